@@ -1,0 +1,162 @@
+/*
+ * rpf_hip.h -- C ABI of librpf_hip.so: the MI355X (gfx950) Random Parameter Filtering pass.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference (tux550/RayTracer-RPF, a
+ * pbrt-v3 fork) has no plugin ABI: its integrator calls the private member
+ *     void RPFIntegrator::ApplyRPFFilter(SamplingFilm&, const int tileSize, int box_size)
+ *                                                   /root/reference/src/custom/rpf.h:91-95, rpf.cpp:497-733
+ * once per box size from RPFIntegrator::Render (rpf.cpp:767-775) and then reduces the filtered samples
+ * into the film (rpf.cpp:779-804).  A maintainer replaces the body of ApplyRPFFilter (or the loop in
+ * Render) with one call to rpf_filter(); INTEGRATION.md shows the binding.  No pbrt type crosses this
+ * boundary: plain pointers, sizes and POD structs only, no exceptions, integer status codes.
+ *
+ * Data layout on both sides of the ABI: 19 SoA planes of fp32, plane d at base + d*H*W*S, element
+ * (y, x, s) at ((y*W)+x)*S + s, dims = SampleData::data (sd.h:62-94):
+ *     0,1 pFilm | 2,3,4 L rgb | 5,6 pLens | 7..9 n0 | 10..12 p0 | 13..15 n1 | 16..18 p1
+ * (the reference stores the same 19 values as doubles in samples[x][y][s], sample_film.cpp:32-42; they
+ * are fp32-valued because pbrt's Float is float.)  Colours travel between passes as fp64 planes on the
+ * device, exactly as the reference carries them in SampleData doubles.
+ *
+ * Threading: one caller thread per rpf_ctx at a time; distinct contexts are independent.
+ * Multi-GPU: one context per device (one process per GPU); a context filters a ROW SLAB
+ * [row_begin,row_end) of a buffer that also holds the halo rows it needs (see raytracer-rpf_amd/slabs.py
+ * for the RCCL neighbour exchange).
+ */
+#ifndef RPF_HIP_H
+#define RPF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPF_NDIM 19
+#define RPF_NFEAT 12
+#define RPF_NPAIR 96
+#define RPF_MAX_BOXES 8
+
+typedef struct rpf_ctx rpf_ctx;
+
+/* status codes; replaces the reference's exit(1) on NaN (rpf.cpp:702-705) and its silent preconditions */
+typedef enum rpf_status {
+    RPF_OK = 0,
+    RPF_E_BADARG = 1,      /* malformed descriptor / NULL pointer / even box / S<=0 ...            */
+    RPF_E_HIP = 2,         /* a HIP runtime call failed; text in rpf_last_error()                  */
+    RPF_E_NONFINITE = 3,   /* REF_ABORT policy: a filtered colour came out NaN (reference aborts)  */
+    RPF_E_NOMEM = 4,
+    RPF_E_UNSUPPORTED = 5, /* neighbourhood too large for the LDS-resident kernel  */
+    RPF_E_NODEVICE = 6
+} rpf_status;
+
+/* which D term feeds W_c_fk[k] for k = 0..11.  rpf.cpp:464 indexes the 3-element D_f_ck with k < 12
+ * (undefined behaviour); the presets name what each build of the reference reads. */
+typedef enum rpf_beta_map {
+    RPF_BETA_REF_GCC11_O3 = 0, /* {Dfc[0..2], 0, Drf[0..7]}         g++ 11.4 -O3 (CMake Release)   */
+    RPF_BETA_REF_GCC11_O2 = 1, /* {Dfc[0..2], 0,0,0,0,0, Drf[0..3]} g++ 11.4 -O0/-O2               */
+    RPF_BETA_PAPER = 2         /* sum_c MI(c_c, f_k): the formula in the comment at rpf.cpp:459    */
+} rpf_beta_map;
+
+typedef enum rpf_degenerate_policy {
+    RPF_DEGEN_REF_ABORT = 0, /* IEEE propagation exactly as the reference; NaN colour => RPF_E_NONFINITE */
+    RPF_DEGEN_EPS = 1        /* documented deviation: +eps in the three denominators of rpf.cpp:464-470,
+                                negative variances clamped to 0, NaN colours fall back to the input    */
+} rpf_degenerate_policy;
+
+enum { RPF_FLAG_NONE = 0, RPF_FLAG_TIMING = 1 /* bracket kernels with hipEvents (rpf_query_counters) */ };
+
+typedef struct rpf_desc {
+    int32_t W;                         /* pixels per row                                            */
+    int32_t H;                         /* rows present in the buffers (owned + halo)                */
+    int32_t S;                         /* samples per pixel, identical for every pixel              */
+    int32_t row_begin;                 /* first row to filter                                       */
+    int32_t row_end;                   /* one past the last row to filter                           */
+    int32_t n_box;                     /* number of passes                                          */
+    int32_t box_sizes[RPF_MAX_BOXES];  /* odd box sizes, one per pass (reference: {7}, rpf.cpp:767)  */
+    int32_t beta_map;                  /* rpf_beta_map                                              */
+    int32_t degenerate_policy;         /* rpf_degenerate_policy                                     */
+    int32_t flags;
+    double eps;                        /* RPF_DEGEN_EPS epsilon (1e-10)                             */
+    double sigma_seed;                 /* rpf.cpp:533: 0.002                                        */
+} rpf_desc;
+
+/* per-pixel stage outputs for parity tests; every pointer may be NULL; indexed [y*W+x] */
+typedef struct rpf_debug {
+    int32_t *nbhd_size;    /* [H*W]      N, stage 1b (rpf.cpp:556-586)                              */
+    double *mean;          /* [H*W*19]   neighbourhood mean,  stage 2 (rpf.cpp:600)                  */
+    double *stddev;        /* [H*W*19]   neighbourhood std,   stage 2 (rpf.cpp:601)                  */
+    double *mi;            /* [H*W*96]   MI values in ComputeCFWeights call order (rpf.cpp:416-442)  */
+    double *alpha;         /* [H*W*3]    rpf.cpp:474-476                                             */
+    double *beta;          /* [H*W*12]   rpf.cpp:478-480                                             */
+    double *wrc;           /* [H*W]      rpf.cpp:483-487                                             */
+    uint32_t *bin_hash;    /* [H*W*19]   FNV-1a over each column's histogram bin ids (mi.cpp:14-16)  */
+    uint32_t *member_hash; /* [H*W]      FNV-1a over the neighbourhood member list, in order         */
+} rpf_debug;
+
+typedef struct rpf_counters {
+    int64_t samples_filtered;   /* (row_end-row_begin)*W*S*n_box of the last call                    */
+    int64_t sum_nbhd;           /* sum over filtered pixels of N, last pass                         */
+    int64_t nonfinite_pixels;   /* pixels whose filtered colour was NaN, all passes                 */
+    int32_t max_nbhd;
+    int32_t first_bad_pixel;    /* y*W+x, -1 if none                                                */
+    float filter_kernel_ms;     /* RPF_FLAG_TIMING: sum over passes of the fused filter kernel      */
+    float stats_kernel_ms;      /* RPF_FLAG_TIMING: sum over passes of the per-pixel stats kernel   */
+    float device_total_ms;      /* RPF_FLAG_TIMING: first launch to last kernel end                 */
+    float h2d_ms;               /* rpf_filter(): host->HBM marshalling, wall clock                  */
+    float d2h_ms;               /* rpf_filter(): HBM->host                                          */
+    int32_t filter_kernel_launches;
+} rpf_counters;
+
+const char *rpf_version(void);
+const char *rpf_status_string(int32_t status);
+
+/* lifetime.  device = HIP device ordinal of this process. */
+int32_t rpf_create(rpf_ctx **out, int32_t device);
+void rpf_destroy(rpf_ctx *ctx);
+const char *rpf_last_error(const rpf_ctx *ctx);
+
+/*
+ * The drop-in call: replaces the `for (box_size : box_sizes) ApplyRPFFilter(...)` loop of
+ * rpf.cpp:767-775 plus the per-pixel reduction of rpf.cpp:779-794 (box reconstruction filter r=0.5).
+ *   planes          host, 19 fp32 planes [19][H][W][S]
+ *   ray_weight      host, [H][W][S] fp32 (SampleData::rayWeight, sd.h:60) or NULL (= 1)
+ *   sample_rgb_out  host, 3 fp32 planes [3][H][W][S] of filtered sample colours, or NULL
+ *   pixel_rgb_out   host, [H][W][3] fp32 mean over s of colour*rayWeight (rows outside the slab: unfiltered), or NULL
+ */
+int32_t rpf_filter(rpf_ctx *ctx, const rpf_desc *desc, const float *planes, const float *ray_weight,
+                   float *sample_rgb_out, float *pixel_rgb_out);
+
+/* Same pass structure with every buffer already resident in HBM (device pointers).  d_colour is 3 fp64
+ * planes [3][H][W][S], read as the input colours and overwritten with the filtered ones; planes 2..4 of
+ * d_planes are ignored.  Runs on `stream` (a hipStream_t, NULL = the context's own stream) and does not
+ * synchronise unless RPF_FLAG_TIMING or the REF_ABORT status check require it (it does: status is read
+ * back at the end). */
+int32_t rpf_filter_device(rpf_ctx *ctx, const rpf_desc *desc, const float *d_planes, double *d_colour,
+                          void *stream);
+
+/* fp32 colour planes (planes 2..4 of d_planes) -> fp64 colour planes; and back, plus the pixel mean */
+int32_t rpf_colour_from_planes_device(rpf_ctx *ctx, const rpf_desc *desc, const float *d_planes,
+                                      double *d_colour, void *stream);
+int32_t rpf_reduce_device(rpf_ctx *ctx, const rpf_desc *desc, const double *d_colour, const float *d_ray_weight,
+                          float *d_sample_rgb_out, float *d_pixel_rgb_out, void *stream);
+
+/* ---- stage-level entry points (host buffers; used by the parity tests) ---------------------------- */
+
+/* stage 1a, FillMeanAndStddev (rpf.cpp:302-353): mean/std [H*W*12] fp64, pixel-major */
+int32_t rpf_stage_pixel_stats(rpf_ctx *ctx, const rpf_desc *desc, const float *planes, double *mean, double *stddev);
+
+/* one pass with one box size; colour_in (3 fp64 planes) may be NULL (= planes 2..4); colour_out 3 fp64
+ * planes; dbg host pointers, any may be NULL */
+int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *desc, int32_t box, const float *planes,
+                              const double *colour_in, double *colour_out, const rpf_debug *dbg);
+
+/* counters of the most recent rpf_filter / rpf_filter_device / rpf_filter_pass_debug call */
+int32_t rpf_query_counters(rpf_ctx *ctx, rpf_counters *out);
+
+/* LDS bytes per workgroup the fused kernel needs for (S, box); > device limit => RPF_E_UNSUPPORTED */
+int64_t rpf_lds_bytes_required(int32_t S, int32_t box);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

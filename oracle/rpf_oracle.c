@@ -1,0 +1,459 @@
+/*
+ * rpf_oracle.c -- CPU restatement (fp64) of the reference RPF filter pass.  TEST INFRASTRUCTURE ONLY
+ * (see rpf_oracle.h).  Every function cites the reference lines it follows; statement order and
+ * floating-point operation order are kept (no reassociation: build with -ffp-contract=off).
+ *
+ * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC)
+ */
+#include "rpf_oracle.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+enum { C_P0 = 0, C_C0 = 2, C_R0 = 5, C_F0 = 7 }; /* column groups, sd.h:62-94,149-214 */
+
+/* ------------------------------------------------------------------------------------------------
+ * pair order = call order of MutualInformation in ComputeCFWeights (rpf.cpp:416-442)
+ * ---------------------------------------------------------------------------------------------- */
+void rpf_oracle_pair_table(int32_t a[RPF_O_NPAIR], int32_t b[RPF_O_NPAIR]) {
+    int p = 0;
+    for (int i = 0; i < 12; ++i) {
+        for (int l = 0; l < 2; ++l) { a[p] = C_F0 + i; b[p] = C_R0 + l; ++p; } /* rpf.cpp:418-422 */
+        for (int l = 0; l < 2; ++l) { a[p] = C_F0 + i; b[p] = C_P0 + l; ++p; } /* rpf.cpp:424-426 */
+    }
+    for (int c = 0; c < 3; ++c) {
+        for (int l = 0; l < 2; ++l) { a[p] = C_C0 + c; b[p] = C_R0 + l; ++p; } /* rpf.cpp:431-433 */
+        for (int l = 0; l < 2; ++l) { a[p] = C_C0 + c; b[p] = C_P0 + l; ++p; } /* rpf.cpp:435-437 */
+        for (int j = 0; j < 12; ++j) { a[p] = C_C0 + c; b[p] = C_F0 + j; ++p; } /* rpf.cpp:439-441 */
+    }
+}
+
+/* x86-64 cvttsd2si semantics of static_cast<int>(double) for NaN / out-of-range (mi.cpp:14,29,35) */
+static int to_int_x86(double v) {
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return INT_MIN;
+    return (int)v;
+}
+
+/* mi.cpp:14-16 / 29-31 / 35-37 */
+static int bin_of(double v, double lo, double hi, int bins) {
+    int bin = to_int_x86((v - lo) / (hi - lo) * bins);
+    if (bins - 1 < bin) bin = bins - 1; /* std::min(bin, bins-1) */
+    if (bin < 0) bin = 0;               /* std::max(bin, 0)      */
+    return bin;
+}
+
+/* std::min_element / std::max_element (first extremum, operator< only) mi.cpp:47-50 */
+static void min_max(const double *v, int n, double *lo, double *hi) {
+    double mn = v[0], mx = v[0];
+    for (int i = 1; i < n; ++i) {
+        if (v[i] < mn) mn = v[i];
+        if (mx < v[i]) mx = v[i];
+    }
+    *lo = mn;
+    *hi = mx;
+}
+
+/* mi.cpp:45-90 with the default bins (= -1) */
+static double mi_scratch(const double *x, const double *y, int n, int *hx, int *hy, int *joint) {
+    double minX, maxX, minY, maxY;
+    min_max(x, n, &minX, &maxX);
+    min_max(y, n, &minY, &maxY);
+    int bins = (int)sqrt((double)n); /* mi.cpp:54,57 */
+    if (bins < 1) bins = 1;
+    memset(hx, 0, sizeof(int) * bins);
+    memset(hy, 0, sizeof(int) * bins);
+    memset(joint, 0, sizeof(int) * bins * bins);
+    /* computeHistogram mi.cpp:5-20 */
+    if (maxX == minX) hx[0] = n; else for (int i = 0; i < n; ++i) hx[bin_of(x[i], minX, maxX, bins)]++;
+    if (maxY == minY) hy[0] = n; else for (int i = 0; i < n; ++i) hy[bin_of(y[i], minY, maxY, bins)]++;
+    /* computeJointHistogram mi.cpp:23-42 */
+    for (int i = 0; i < n; ++i) {
+        int bx = 0, by = 0;
+        if (maxX != minX) bx = bin_of(x[i], minX, maxX, bins);
+        if (maxY != minY) by = bin_of(y[i], minY, maxY, bins);
+        joint[bx * bins + by]++;
+    }
+    double total = (double)n; /* mi.cpp:66 */
+    double mi = 0.0;
+    for (int i = 0; i < bins; ++i) {
+        double pX = hx[i] / total; /* mi.cpp:70-72 */
+        for (int j = 0; j < bins; ++j) {
+            double pY = hy[j] / total;
+            double pXY = joint[i * bins + j] / total; /* mi.cpp:81 */
+            double pp = pX * pY;
+            if (pXY > 0 && pp != 0) mi += pXY * log(pXY / pp); /* mi.cpp:83-85 */
+        }
+    }
+    return mi;
+}
+
+double rpf_oracle_mi(const double *x, const double *y, int32_t n) {
+    int bins = (int)sqrt((double)n);
+    if (bins < 1) bins = 1;
+    int *buf = (int *)malloc(sizeof(int) * (size_t)(2 * bins + bins * bins));
+    double r = mi_scratch(x, y, n, buf, buf + bins, buf + 2 * bins);
+    free(buf);
+    return r;
+}
+
+/* ops.h:111-144 : getMean then getStdDev, sequential sums */
+void rpf_oracle_mean_std(const double *rows, int32_t n, int32_t ncols, double *mean, double *stddev) {
+    for (int c = 0; c < ncols; ++c) { mean[c] = 0; stddev[c] = 0; }
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < ncols; ++c) mean[c] = mean[c] + rows[(size_t)i * ncols + c]; /* ops.h:121 */
+    for (int c = 0; c < ncols; ++c) mean[c] = mean[c] / (double)n;                         /* ops.h:123 */
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < ncols; ++c) {
+            double v = rows[(size_t)i * ncols + c];
+            stddev[c] = stddev[c] + v * v; /* ops.h:138 */
+        }
+    for (int c = 0; c < ncols; ++c) stddev[c] = sqrt(stddev[c] / (double)n - mean[c] * mean[c]); /* ops.h:141 */
+}
+
+static size_t plane_stride(const rpf_oracle_desc *d) { return (size_t)d->H * d->W * d->S; }
+static size_t sample_off(const rpf_oracle_desc *d, int y, int x, int s) {
+    return ((size_t)y * d->W + x) * d->S + s;
+}
+
+static void clamp_var_eps(double *sd, int n, int policy) {
+    /* EPS policy: a variance that rounds below zero is treated as zero (sqrt(-tiny)=NaN otherwise) */
+    if (policy != RPF_O_DEGEN_EPS) return;
+    for (int c = 0; c < n; ++c)
+        if (isnan(sd[c])) sd[c] = 0.0;
+}
+
+/* rpf.cpp:338-347 for one pixel */
+static void pixel_feature_stats(const rpf_oracle_desc *d, const float *planes, int y, int x, double *m12,
+                                double *sd12) {
+    const size_t ps = plane_stride(d);
+    double *r = (double *)malloc(sizeof(double) * (size_t)d->S * RPF_O_NFEAT);
+    for (int s = 0; s < d->S; ++s)
+        for (int k = 0; k < RPF_O_NFEAT; ++k) r[s * RPF_O_NFEAT + k] = planes[(C_F0 + k) * ps + sample_off(d, y, x, s)];
+    rpf_oracle_mean_std(r, d->S, RPF_O_NFEAT, m12, sd12);
+    clamp_var_eps(sd12, RPF_O_NFEAT, d->degenerate_policy);
+    free(r);
+}
+
+void rpf_oracle_pixel_stats(const rpf_oracle_desc *d, const float *planes, double *mean, double *stddev) {
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < d->H; ++y)
+        for (int x = 0; x < d->W; ++x) {
+            size_t p = (size_t)y * d->W + x;
+            pixel_feature_stats(d, planes, y, x, mean + p * RPF_O_NFEAT, stddev + p * RPF_O_NFEAT);
+        }
+}
+
+/* rpf.cpp:356-488 on a normalised neighbourhood (z: n x 19, row major) */
+typedef struct {
+    double *col[RPF_O_NDIM]; /* 19 column vectors of length n (rpf.cpp:381-412) */
+    int *hx, *hy, *joint;
+} cf_scratch;
+
+static void cf_weights_core(const double *z, int n, int beta_map, int policy, double eps, cf_scratch *sc,
+                            double alpha[3], double beta[12], double *wrc, double *mi96) {
+    for (int c = 0; c < RPF_O_NDIM; ++c)
+        for (int i = 0; i < n; ++i) sc->col[c][i] = z[(size_t)i * RPF_O_NDIM + c];
+
+    double D_r_fk[12], D_p_fk[12], D_r_ck[3], D_p_ck[3], D_f_ck[3]; /* rpf.cpp:363-377 */
+    double D_cf_k[12];                                              /* sum_c MI(c_c,f_k): PAPER numerator */
+    for (int i = 0; i < 12; ++i) { D_r_fk[i] = 0; D_p_fk[i] = 0; D_cf_k[i] = 0; }
+    for (int i = 0; i < 3; ++i) { D_r_ck[i] = 0; D_p_ck[i] = 0; D_f_ck[i] = 0; }
+
+    int p = 0;
+    double v;
+    for (int i = 0; i < 12; ++i) { /* rpf.cpp:416-427 */
+        for (int j = 0; j < 2; ++j) {
+            v = mi_scratch(sc->col[C_F0 + i], sc->col[C_R0 + j], n, sc->hx, sc->hy, sc->joint);
+            D_r_fk[i] += v;
+            if (mi96) mi96[p] = v;
+            ++p;
+        }
+        for (int j = 0; j < 2; ++j) {
+            v = mi_scratch(sc->col[C_F0 + i], sc->col[C_P0 + j], n, sc->hx, sc->hy, sc->joint);
+            D_p_fk[i] += v;
+            if (mi96) mi96[p] = v;
+            ++p;
+        }
+    }
+    for (int i = 0; i < 3; ++i) { /* rpf.cpp:429-442 */
+        for (int j = 0; j < 2; ++j) {
+            v = mi_scratch(sc->col[C_C0 + i], sc->col[C_R0 + j], n, sc->hx, sc->hy, sc->joint);
+            D_r_ck[i] += v;
+            if (mi96) mi96[p] = v;
+            ++p;
+        }
+        for (int j = 0; j < 2; ++j) {
+            v = mi_scratch(sc->col[C_C0 + i], sc->col[C_P0 + j], n, sc->hx, sc->hy, sc->joint);
+            D_p_ck[i] += v;
+            if (mi96) mi96[p] = v;
+            ++p;
+        }
+        for (int j = 0; j < 12; ++j) {
+            v = mi_scratch(sc->col[C_C0 + i], sc->col[C_F0 + j], n, sc->hx, sc->hy, sc->joint);
+            D_f_ck[i] += v;
+            D_cf_k[j] += v;
+            if (mi96) mi96[p] = v;
+            ++p;
+        }
+    }
+
+    double D_f_c = 0, D_r_c = 0, D_p_c = 0; /* rpf.cpp:449-456 */
+    for (int i = 0; i < 3; ++i) { D_f_c += D_f_ck[i]; D_r_c += D_r_ck[i]; D_p_c += D_p_ck[i]; }
+
+    const double e = (policy == RPF_O_DEGEN_EPS) ? eps : 0.0;
+    double num[12]; /* what rpf.cpp:464 reads as D_f_ck[i], i<12, on a 3-array */
+    for (int k = 0; k < 12; ++k) {
+        switch (beta_map) {
+        case RPF_O_BETA_REF_GCC11_O2: num[k] = k < 3 ? D_f_ck[k] : (k < 8 ? 0.0 : D_r_fk[k - 8]); break;
+        case RPF_O_BETA_PAPER: num[k] = D_cf_k[k]; break;
+        default: num[k] = k < 3 ? D_f_ck[k] : (k < 4 ? 0.0 : D_r_fk[k - 4]); break;
+        }
+    }
+    double W_c_fk[12], W_r_fk[12], W_r_ck[3];
+    for (int i = 0; i < 12; ++i) { /* rpf.cpp:463-466 */
+        W_c_fk[i] = num[i] / (D_f_c + D_r_c + D_p_c + e);
+        W_r_fk[i] = D_r_fk[i] / (D_r_fk[i] + D_p_fk[i] + e);
+    }
+    for (int i = 0; i < 3; ++i) W_r_ck[i] = D_r_ck[i] / (D_r_ck[i] + D_p_ck[i] + e); /* rpf.cpp:469-471 */
+    for (int i = 0; i < 3; ++i) alpha[i] = 1 - W_r_ck[i];                            /* rpf.cpp:474-476 */
+    for (int i = 0; i < 12; ++i) beta[i] = (1 - W_r_fk[i]) * W_c_fk[i];              /* rpf.cpp:478-480 */
+    double w = 0;                                                                    /* rpf.cpp:483-487 */
+    for (int i = 0; i < 3; ++i) w += W_r_ck[i];
+    w /= 3;
+    *wrc = w;
+}
+
+static void cf_scratch_alloc(cf_scratch *sc, int nmax) {
+    int bins = (int)sqrt((double)nmax) + 1;
+    for (int c = 0; c < RPF_O_NDIM; ++c) sc->col[c] = (double *)malloc(sizeof(double) * (size_t)nmax);
+    sc->hx = (int *)malloc(sizeof(int) * (size_t)(2 * bins + bins * bins));
+    sc->hy = sc->hx + bins;
+    sc->joint = sc->hy + bins;
+}
+static void cf_scratch_free(cf_scratch *sc) {
+    for (int c = 0; c < RPF_O_NDIM; ++c) free(sc->col[c]);
+    free(sc->hx);
+}
+
+void rpf_oracle_cf_weights(const double *z, int32_t n, int32_t beta_map, int32_t policy, double eps,
+                           double alpha[3], double beta[12], double *wrc, double *mi96) {
+    cf_scratch sc;
+    cf_scratch_alloc(&sc, n);
+    cf_weights_core(z, n, beta_map, policy, eps, &sc, alpha, beta, wrc, mi96);
+    cf_scratch_free(&sc);
+}
+
+static uint32_t fnv1a_u32(uint32_t h, uint32_t v) {
+    for (int i = 0; i < 4; ++i) { h ^= (v >> (8 * i)) & 0xffu; h *= 16777619u; }
+    return h;
+}
+static uint32_t fnv1a_u16(uint32_t h, uint32_t v) {
+    for (int i = 0; i < 2; ++i) { h ^= (v >> (8 * i)) & 0xffu; h *= 16777619u; }
+    return h;
+}
+
+void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const double *colour_in,
+                            double *colour_out, rpf_oracle_debug *dbg, rpf_oracle_result *res) {
+    const int W = d->W, H = d->H, S = d->S, box = d->box;
+    const int b = (box - 1) / 2; /* rpf.cpp:561 */
+    const size_t ps = plane_stride(d);
+    const int nmax = box * box * S;
+    const double sigma_p = (double)(box / 4); /* rpf.cpp:531: integer division */
+    const double seed = d->sigma_seed;        /* rpf.cpp:533 */
+
+    /* rows outside the filtered range pass through */
+    for (int c = 0; c < 3; ++c)
+        for (size_t i = 0; i < ps; ++i)
+            colour_out[c * ps + i] = colour_in ? colour_in[c * ps + i] : (double)planes[(C_C0 + c) * ps + i];
+
+    /* stage 1a for every pixel of the buffer (rpf.cpp:519) */
+    double *pmean = (double *)malloc(sizeof(double) * (size_t)H * W * RPF_O_NFEAT);
+    double *pstd = (double *)malloc(sizeof(double) * (size_t)H * W * RPF_O_NFEAT);
+    rpf_oracle_pixel_stats(d, planes, pmean, pstd);
+
+    int32_t first_bad = INT_MAX, max_n = 0;
+    int64_t n_bad = 0, sum_n = 0;
+
+#ifdef _OPENMP
+    if (d->n_threads > 0) omp_set_num_threads(d->n_threads);
+#endif
+#pragma omp parallel
+    {
+        double *nb = (double *)malloc(sizeof(double) * (size_t)nmax * RPF_O_NDIM);  /* raw neighbourhood */
+        double *z = (double *)malloc(sizeof(double) * (size_t)nmax * RPF_O_NDIM);   /* normalised */
+        double *zo = (double *)malloc(sizeof(double) * (size_t)S * RPF_O_NDIM);     /* normalised own */
+        double *wm = (double *)malloc(sizeof(double) * (size_t)S * nmax);           /* weights_mat */
+        uint32_t *code = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nmax);
+        cf_scratch sc;
+        cf_scratch_alloc(&sc, nmax);
+        int32_t t_first = INT_MAX, t_max = 0;
+        int64_t t_bad = 0, t_sum = 0;
+
+#pragma omp for schedule(dynamic, 1)
+        for (int y = d->row_begin; y < d->row_end; ++y) {
+            for (int x = 0; x < W; ++x) {
+                const size_t pix = (size_t)y * W + x;
+                const double *m12 = pmean + pix * RPF_O_NFEAT;
+                const double *s12 = pstd + pix * RPF_O_NFEAT;
+                int n = 0;
+                /* own samples first, unconditionally (rpf.cpp:558) */
+                for (int s = 0; s < S; ++s) {
+                    size_t o = sample_off(d, y, x, s);
+                    for (int c = 0; c < RPF_O_NDIM; ++c) nb[(size_t)n * RPF_O_NDIM + c] = planes[c * ps + o];
+                    if (colour_in)
+                        for (int c = 0; c < 3; ++c) nb[(size_t)n * RPF_O_NDIM + C_C0 + c] = colour_in[c * ps + o];
+                    code[n] = (uint32_t)((b * box + b) * S + s);
+                    ++n;
+                }
+                /* rpf.cpp:562-586: xn outer ascending, yn inner ascending */
+                for (int xn = x - b; xn <= x + b; ++xn) {
+                    for (int yn = y - b; yn <= y + b; ++yn) {
+                        if (xn == x && yn == y) continue;
+                        if (xn < 0 || xn >= W || yn < 0 || yn >= H) continue;
+                        for (int s = 0; s < S; ++s) {
+                            size_t o = sample_off(d, yn, xn, s);
+                            int within = 1;
+                            for (int k = 0; k < RPF_O_NFEAT; ++k) { /* ops.h:99-107 : fail iff a >= b */
+                                double a = fabs((double)planes[(C_F0 + k) * ps + o] - m12[k]);
+                                double lim = s12[k] * 3; /* rpf.cpp:579 */
+                                if (a >= lim) { within = 0; break; }
+                            }
+                            if (!within) continue;
+                            for (int c = 0; c < RPF_O_NDIM; ++c) nb[(size_t)n * RPF_O_NDIM + c] = planes[c * ps + o];
+                            if (colour_in)
+                                for (int c = 0; c < 3; ++c)
+                                    nb[(size_t)n * RPF_O_NDIM + C_C0 + c] = colour_in[c * ps + o];
+                            code[n] = (uint32_t)(((xn - x + b) * box + (yn - y + b)) * S + s);
+                            ++n;
+                        }
+                    }
+                }
+                t_sum += n;
+                if (n > t_max) t_max = n;
+
+                /* stage 2: rpf.cpp:596-612 */
+                double M[RPF_O_NDIM], SD[RPF_O_NDIM];
+                rpf_oracle_mean_std(nb, n, RPF_O_NDIM, M, SD);
+                clamp_var_eps(SD, RPF_O_NDIM, d->degenerate_policy);
+                for (int i = 0; i < n; ++i)
+                    for (int c = 0; c < RPF_O_NDIM; ++c) { /* sd.h:229-232, ops.h:48 */
+                        double a = nb[(size_t)i * RPF_O_NDIM + c] - M[c];
+                        z[(size_t)i * RPF_O_NDIM + c] = SD[c] == 0 ? 0 : a / SD[c];
+                    }
+                for (int i = 0; i < S; ++i) /* own samples are entries 0..S-1 of the neighbourhood */
+                    for (int c = 0; c < RPF_O_NDIM; ++c) zo[i * RPF_O_NDIM + c] = z[(size_t)i * RPF_O_NDIM + c];
+
+                /* stage 3: rpf.cpp:615-623 */
+                double alpha[3], beta[12], wrc;
+                double *mi_out = (dbg && dbg->mi) ? dbg->mi + pix * RPF_O_NPAIR : NULL;
+                cf_weights_core(z, n, d->beta_map, d->degenerate_policy, d->eps, &sc, alpha, beta, &wrc, mi_out);
+
+                if (dbg) {
+                    if (dbg->nbhd_size) dbg->nbhd_size[pix] = n;
+                    if (dbg->mean) memcpy(dbg->mean + pix * RPF_O_NDIM, M, sizeof(M));
+                    if (dbg->stddev) memcpy(dbg->stddev + pix * RPF_O_NDIM, SD, sizeof(SD));
+                    if (dbg->alpha) memcpy(dbg->alpha + pix * 3, alpha, sizeof(alpha));
+                    if (dbg->beta) memcpy(dbg->beta + pix * 12, beta, sizeof(beta));
+                    if (dbg->wrc) dbg->wrc[pix] = wrc;
+                    if (dbg->member_hash) {
+                        uint32_t h = 2166136261u;
+                        for (int i = 0; i < n; ++i) h = fnv1a_u32(h, code[i]);
+                        dbg->member_hash[pix] = h;
+                    }
+                    if (dbg->bin_hash) {
+                        int bins = (int)sqrt((double)n);
+                        if (bins < 1) bins = 1;
+                        for (int c = 0; c < RPF_O_NDIM; ++c) {
+                            double lo, hi;
+                            min_max(sc.col[c], n, &lo, &hi);
+                            uint32_t h = 2166136261u;
+                            for (int i = 0; i < n; ++i)
+                                h = fnv1a_u16(h, (uint32_t)(hi == lo ? 0 : bin_of(sc.col[c][i], lo, hi, bins)));
+                            dbg->bin_hash[pix * RPF_O_NDIM + c] = h;
+                        }
+                    }
+                }
+
+                /* stage 4a: rpf.cpp:637-678 */
+                double sigma_c_squared = seed * seed / (1 - wrc) / (1 - wrc); /* rpf.cpp:662 */
+                double sigma_f_squared = sigma_c_squared;
+                double sigma_p_squared = sigma_p * sigma_p;
+                for (int i = 0; i < S; ++i) {
+                    const double *si = zo + i * RPF_O_NDIM;
+                    for (int j = 0; j < n; ++j) {
+                        const double *sj = z + (size_t)j * RPF_O_NDIM;
+                        double sp = 0, scol = 0, sf = 0;
+                        for (int k = 0; k < 2; ++k) { double t = si[C_P0 + k] - sj[C_P0 + k]; sp += t * t; }
+                        for (int k = 0; k < 3; ++k) { double t = si[C_C0 + k] - sj[C_C0 + k]; scol += (t * t) * alpha[k]; }
+                        for (int k = 0; k < 12; ++k) { double t = si[C_F0 + k] - sj[C_F0 + k]; sf += (t * t) * beta[k]; }
+                        wm[(size_t)i * n + j] = exp(-sp / (2 * sigma_p_squared)) * exp(-scol / (2 * sigma_c_squared)) *
+                                                exp(-sf / (2 * sigma_f_squared)); /* rpf.cpp:667-670 */
+                    }
+                }
+                /* stage 4b: rpf.cpp:682-717 */
+                int bad = 0;
+                for (int i = 0; i < S; ++i) {
+                    size_t o = sample_off(d, y, x, i);
+                    for (int k = 0; k < 3; ++k) {
+                        double sum_w = 0, sum_w_c = 0;
+                        for (int j = 0; j < n; ++j) {
+                            sum_w += wm[(size_t)i * n + j];
+                            sum_w_c += wm[(size_t)i * n + j] * nb[(size_t)j * RPF_O_NDIM + C_C0 + k];
+                        }
+                        double prime = sum_w_c / sum_w;
+                        if (isnan(prime)) { /* rpf.cpp:702-705: exit(1) in the reference */
+                            bad = 1;
+                            if (d->degenerate_policy == RPF_O_DEGEN_EPS) prime = nb[(size_t)i * RPF_O_NDIM + C_C0 + k];
+                        }
+                        colour_out[k * ps + o] = prime;
+                    }
+                }
+                if (bad) {
+                    ++t_bad;
+                    if ((int32_t)pix < t_first) t_first = (int32_t)pix;
+                }
+            }
+        }
+#pragma omp critical
+        {
+            if (t_first < first_bad) first_bad = t_first;
+            if (t_max > max_n) max_n = t_max;
+            n_bad += t_bad;
+            sum_n += t_sum;
+        }
+        cf_scratch_free(&sc);
+        free(nb); free(z); free(zo); free(wm); free(code);
+    }
+    free(pmean);
+    free(pstd);
+    if (res) {
+        res->nonfinite_pixels = n_bad;
+        res->first_bad_pixel = n_bad ? first_bad : -1;
+        res->status = (n_bad && d->degenerate_policy == RPF_O_DEGEN_REF_ABORT) ? 1 : 0;
+        res->sum_nbhd = sum_n;
+        res->max_nbhd = max_n;
+        res->reserved = 0;
+    }
+}
+
+/* rpf.cpp:783-794 with the default box reconstruction filter (radius 0.5, film.h:121-161): every sample
+ * lands in its own pixel with filter weight 1, so the pixel value is sum(L*rayWeight)/sum(1). */
+void rpf_oracle_pixel_mean(const rpf_oracle_desc *d, const double *colour, const float *ray_weight,
+                           double *pixel_rgb) {
+    const size_t ps = plane_stride(d);
+    for (int y = d->row_begin; y < d->row_end; ++y)
+        for (int x = 0; x < d->W; ++x)
+            for (int c = 0; c < 3; ++c) {
+                double acc = 0;
+                for (int s = 0; s < d->S; ++s) {
+                    size_t o = sample_off(d, y, x, s);
+                    acc += colour[c * ps + o] * (ray_weight ? (double)ray_weight[o] : 1.0);
+                }
+                pixel_rgb[((size_t)y * d->W + x) * 3 + c] = acc / (double)d->S;
+            }
+}

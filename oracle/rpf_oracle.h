@@ -1,0 +1,126 @@
+/*
+ * rpf_oracle.h -- CPU restatement (fp64, plain C) of the reference's RPF filter pass.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
+ * checker / the reported CPU baseline.  The product path (raytracer-rpf_amd/csrc -> librpf_hip.so)
+ * never links, loads or calls it.
+ *
+ * What is restated (reference = /root/reference, tux550/RayTracer-RPF):
+ *   stage 1a  per-pixel feature mean/std      src/custom/rpf.cpp:302-353, src/custom/ops.h:111-144
+ *   stage 1b  3-sigma neighbourhood gather    src/custom/rpf.cpp:556-586, src/custom/ops.h:99-107
+ *   stage 2   neighbourhood normalisation     src/custom/rpf.cpp:596-612, src/custom/sd.h:224-235, ops.h:44-51
+ *   stage 3   mutual-information weights      src/custom/rpf.cpp:356-488, src/custom/mi.cpp:5-90
+ *   stage 4   cross-bilateral weights + blend src/custom/rpf.cpp:627-717
+ *   epilogue  film swap / multi-pass loop     src/custom/rpf.cpp:719-733, 767-775
+ *   reduction per-pixel mean of L*rayWeight   src/custom/rpf.cpp:779-794 (box filter r=0.5 case)
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - rpf_oracle_mi / rpf_oracle_mean_std are checked bit-for-bit against the REAL reference code
+ *     (mi.cpp + ops.h compiled from /root/reference into oracle/_ref/libref_mi.so) in this container,
+ *     and against golden vectors generated from that build (tests/golden/).
+ *   - the glue around them (gather order, ComputeCFWeights algebra, weights, blend) lives in rpf.cpp,
+ *     which cannot be compiled here without stand-ins for glog/OpenEXR (absent submodules), and the
+ *     reference holds no test or fixture for it: that part is "parity unpinned" and follows the cited
+ *     lines statement by statement.
+ *
+ * Data layout (identical to the device layout): SoA planes, plane d at base + d*H*W*S,
+ * element (y, x, s) at ((y*W)+x)*S + s.  The 19 dims are those of SampleData (sd.h:62-94):
+ *   0,1 pFilm | 2,3,4 L rgb | 5,6 pLens | 7..9 n0 | 10..12 p0 | 13..15 n1 | 16..18 p1
+ */
+#ifndef RPF_ORACLE_H
+#define RPF_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPF_O_NDIM 19
+#define RPF_O_NFEAT 12
+#define RPF_O_NPAIR 96
+
+/* beta numerator presets: which D term feeds W_c_fk[k] (rpf.cpp:464 reads a 3-array at k<12: UB) */
+enum {
+    RPF_O_BETA_REF_GCC11_O3 = 0, /* {Dfc[0..2], 0, Drf[0..7]}  (-O3 = CMake Release) */
+    RPF_O_BETA_REF_GCC11_O2 = 1, /* {Dfc[0..2], 0,0,0,0,0, Drf[0..3]} */
+    RPF_O_BETA_PAPER = 2         /* sum_c MI(c_c, f_k) (intent of rpf.cpp:459) */
+};
+
+enum {
+    RPF_O_DEGEN_REF_ABORT = 0, /* IEEE propagation; first non-finite pixel reported (rpf.cpp:702-705) */
+    RPF_O_DEGEN_EPS = 1        /* documented deviation: eps in the three denominators, var clamped >= 0 */
+};
+
+typedef struct rpf_oracle_desc {
+    int32_t W;         /* pixels per row */
+    int32_t H;         /* rows present in the buffers (owned rows + halo rows) */
+    int32_t S;         /* samples per pixel (every pixel has exactly S) */
+    int32_t row_begin; /* first row to filter */
+    int32_t row_end;   /* one past the last row to filter */
+    int32_t box;       /* odd box size (reference enables 7, rpf.cpp:767) */
+    int32_t beta_map;
+    int32_t degenerate_policy;
+    double eps;        /* used by RPF_O_DEGEN_EPS (1e-10) */
+    double sigma_seed; /* rpf.cpp:533 : 0.002 */
+    int32_t n_threads; /* 0 = all cores (OpenMP) */
+    int32_t reserved;
+} rpf_oracle_desc;
+
+/* optional per-pixel debug planes; any pointer may be NULL. Indexed [y*W+x] (rows outside
+ * [row_begin,row_end) untouched). */
+typedef struct rpf_oracle_debug {
+    int32_t *nbhd_size;   /* [H*W]        N                                        */
+    double *mean;         /* [H*W*19]     neighbourhood mean M                     */
+    double *stddev;       /* [H*W*19]     neighbourhood std  SD                    */
+    double *mi;           /* [H*W*96]     the 96 MI values, order: see rpf_oracle.c */
+    double *alpha;        /* [H*W*3]                                                */
+    double *beta;         /* [H*W*12]                                               */
+    double *wrc;          /* [H*W]                                                  */
+    uint32_t *bin_hash;   /* [H*W*19]     FNV-1a over the bin ids of each column   */
+    uint32_t *member_hash;/* [H*W]        FNV-1a over the member (dx,dy,s) triples  */
+} rpf_oracle_debug;
+
+typedef struct rpf_oracle_result {
+    int32_t status;          /* 0 ok, 1 non-finite output encountered */
+    int32_t first_bad_pixel; /* y*W+x of the lowest-index offending pixel, -1 if none */
+    int64_t nonfinite_pixels;
+    int64_t sum_nbhd;        /* sum over filtered pixels of N */
+    int32_t max_nbhd;
+    int32_t reserved;
+} rpf_oracle_result;
+
+/* A4: histogram mutual information of two length-n vectors (mi.cpp:45-90, bins = -1 defaults). */
+double rpf_oracle_mi(const double *x, const double *y, int32_t n);
+
+/* ops.h:111-144 on an n x ncols row-major matrix: sequential sums, population std = sqrt(E[x^2]-m^2). */
+void rpf_oracle_mean_std(const double *rows, int32_t n, int32_t ncols, double *mean, double *stddev);
+
+/* A1: per-pixel mean/std of the 12 features over the pixel's own S samples. Output [H*W*12] each. */
+void rpf_oracle_pixel_stats(const rpf_oracle_desc *d, const float *planes, double *mean, double *stddev);
+
+/* A5 on an already normalised neighbourhood: z is n x 19 row-major. mi96 may be NULL. */
+void rpf_oracle_cf_weights(const double *z, int32_t n, int32_t beta_map, int32_t policy, double eps,
+                           double alpha[3], double beta[12], double *wrc, double *mi96);
+
+/* One filter pass (A1..A8) for one box size.
+ *   planes     19 fp32 planes (colour planes 2..4 used unless colour_in != NULL)
+ *   colour_in  optional 3 fp64 planes [c][y][x][s] (colours produced by a previous pass)
+ *   colour_out 3 fp64 planes; rows outside [row_begin,row_end) are copied from the input colours
+ */
+void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const double *colour_in,
+                            double *colour_out, rpf_oracle_debug *dbg, rpf_oracle_result *res);
+
+/* A9 (box r=0.5): pixel_rgb[(y*W+x)*3+c] = mean_s(colour[c][y][x][s] * ray_weight[y][x][s]);
+ * ray_weight may be NULL (=1). */
+void rpf_oracle_pixel_mean(const rpf_oracle_desc *d, const double *colour, const float *ray_weight,
+                           double *pixel_rgb);
+
+/* pair order of the 96 MI values (a,b column indices in the 19-vector) */
+void rpf_oracle_pair_table(int32_t a[RPF_O_NPAIR], int32_t b[RPF_O_NPAIR]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

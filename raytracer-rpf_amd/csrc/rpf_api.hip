@@ -1,0 +1,446 @@
+// rpf_api.hip -- the C ABI of include/rpf_hip.h: context, HBM workspace, pass sequencing, status and
+// counters.  The pass loop mirrors RPFIntegrator::Render (rpf.cpp:767-775): for each box size run
+// FillMeanAndStddev (stage 1a) then the fused filter; filtered colours replace the film's colours
+// (rpf.cpp:732) and feed the next pass.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rpf_internal.h"
+
+using namespace rpf;
+
+struct rpf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // grow-only HBM workspace
+    float *d_planes = nullptr;   size_t cap_planes = 0;   // 19 planes fp32
+    float *d_rayw = nullptr;     size_t cap_rayw = 0;
+    double *d_colA = nullptr;    size_t cap_colA = 0;     // 3 planes fp64
+    double *d_colB = nullptr;    size_t cap_colB = 0;
+    double *d_pmean = nullptr;   size_t cap_pmean = 0;    // [12][H*W]
+    double *d_pstd = nullptr;    size_t cap_pstd = 0;
+    int32_t *d_nbhd = nullptr;   size_t cap_nbhd = 0;
+    double *d_tlogt = nullptr;   size_t cap_tlogt = 0;    int tlogt_n = 0;
+    float *d_srgb = nullptr;     size_t cap_srgb = 0;
+    float *d_prgb = nullptr;     size_t cap_prgb = 0;
+    int32_t *d_status = nullptr;                           // [0] bad count [1] first bad
+    unsigned long long *d_nred = nullptr;                  // [0] sum N [1] max N
+    // debug planes
+    void *d_dbg[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap_dbg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    rpf_counters counters{};
+};
+
+namespace {
+
+int32_t fail(rpf_ctx *c, int32_t st, const std::string &msg) {
+    if (c) c->err = msg;
+    return st;
+}
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return fail(ctx, RPF_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+template <class T>
+int32_t ensure(rpf_ctx *ctx, T *&ptr, size_t &cap, size_t bytes) {
+    if (bytes <= cap && ptr) return RPF_OK;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void **)&ptr, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? RPF_E_NOMEM : RPF_E_HIP,
+                                     std::string("hipMalloc: ") + hipGetErrorString(e));
+    cap = bytes;
+    return RPF_OK;
+}
+
+int32_t validate(rpf_ctx *ctx, const rpf_desc *d, bool need_boxes) {
+    if (!ctx) return RPF_E_BADARG;
+    if (!d) return fail(ctx, RPF_E_BADARG, "desc is NULL");
+    if (d->W <= 0 || d->H <= 0 || d->S <= 0) return fail(ctx, RPF_E_BADARG, "W, H, S must be positive");
+    if (d->row_begin < 0 || d->row_end > d->H || d->row_begin > d->row_end)
+        return fail(ctx, RPF_E_BADARG, "row range must satisfy 0 <= row_begin <= row_end <= H");
+    if ((uint64_t)d->W * d->H * d->S >= (1ull << 32))
+        return fail(ctx, RPF_E_BADARG, "W*H*S must be < 2^32 per slab (split the image into row slabs)");
+    if (d->beta_map < 0 || d->beta_map > RPF_BETA_PAPER) return fail(ctx, RPF_E_BADARG, "unknown beta_map");
+    if (d->degenerate_policy < 0 || d->degenerate_policy > RPF_DEGEN_EPS)
+        return fail(ctx, RPF_E_BADARG, "unknown degenerate_policy");
+    if (need_boxes) {
+        if (d->n_box < 1 || d->n_box > RPF_MAX_BOXES) return fail(ctx, RPF_E_BADARG, "n_box must be 1..8");
+        for (int i = 0; i < d->n_box; ++i)
+            if (d->box_sizes[i] < 1 || (d->box_sizes[i] & 1) == 0)
+                return fail(ctx, RPF_E_BADARG, "box sizes must be odd and positive (rpf.cpp:561)");
+    }
+    return RPF_OK;
+}
+
+int32_t ensure_tlogt(rpf_ctx *ctx, int nmax) {
+    if (ctx->d_tlogt && ctx->tlogt_n >= nmax + 1) return RPF_OK;
+    std::vector<double> t((size_t)nmax + 1);
+    t[0] = 0.0;
+    for (int k = 1; k <= nmax; ++k) t[k] = (double)k * std::log((double)k);
+    int32_t st = ensure(ctx, ctx->d_tlogt, ctx->cap_tlogt, t.size() * sizeof(double));
+    if (st) return st;
+    HIP_TRY(hipMemcpy(ctx->d_tlogt, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    ctx->tlogt_n = nmax + 1;
+    return RPF_OK;
+}
+
+struct PassSetup {
+    PassParams p;
+    uint32_t lds = 0;
+};
+
+int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const float *d_planes, const double *col_in,
+                   double *col_out, const rpf_debug *dbg_dev, PassSetup &out) {
+    if (box < 1 || (box & 1) == 0) return fail(ctx, RPF_E_BADARG, "box must be odd and positive");
+    PassParams &p = out.p;
+    std::memset(&p, 0, sizeof(p));
+    p.W = d->W; p.H = d->H; p.S = d->S;
+    p.row_begin = d->row_begin; p.row_end = d->row_end;
+    p.box = box; p.b = (box - 1) / 2;
+    p.beta_map = d->beta_map; p.policy = d->degenerate_policy;
+    const int64_t nmax64 = (int64_t)box * box * d->S;
+    if (nmax64 > 49 * 64) return fail(ctx, RPF_E_UNSUPPORTED, "box*box*S > 3136: neighbourhood too large for the wave-per-pixel kernel");
+    p.nmax = (int)nmax64;
+    p.nmax_pad = (p.nmax + 15) / 16 * 16;
+    p.bmax = (int)std::sqrt((double)p.nmax);
+    if (p.bmax < 1) p.bmax = 1;
+    p.eps = d->eps; p.seed = d->sigma_seed;
+    p.sigma_p = (double)(box / 4); // rpf.cpp:531: integer division
+    p.plane_stride = (uint64_t)d->W * d->H * d->S;
+    p.planes = d_planes; p.col_in = col_in; p.col_out = col_out;
+    const size_t HW = (size_t)d->W * d->H;
+    int32_t st;
+    if ((st = ensure(ctx, ctx->d_pmean, ctx->cap_pmean, HW * kNFeat * sizeof(double)))) return st;
+    if ((st = ensure(ctx, ctx->d_pstd, ctx->cap_pstd, HW * kNFeat * sizeof(double)))) return st;
+    if ((st = ensure(ctx, ctx->d_nbhd, ctx->cap_nbhd, HW * sizeof(int32_t)))) return st;
+    if ((st = ensure_tlogt(ctx, p.nmax))) return st;
+    p.pmean = ctx->d_pmean; p.pstd = ctx->d_pstd; p.tlogt = ctx->d_tlogt;
+    p.nbhd = ctx->d_nbhd; p.status = ctx->d_status;
+    if (dbg_dev) p.dbg = *dbg_dev;
+    const bool t_in_lds = (uint32_t)(p.nmax + 1) * 8u <= 8192u;
+    out.lds = lds_layout(p.S, p.nmax, p.nmax_pad, p.bmax, t_in_lds).total;
+    if ((int)out.lds > max_lds_per_block())
+        return fail(ctx, RPF_E_UNSUPPORTED, "neighbourhood working set exceeds 160 KiB of LDS");
+    return RPF_OK;
+}
+
+// runs all passes of desc on device-resident buffers; colour ends up in d_colour
+int32_t run_passes(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, double *d_colour, hipStream_t s) {
+    const bool timing = (d->flags & RPF_FLAG_TIMING) != 0;
+    const size_t ps = (size_t)d->W * d->H * d->S;
+    int32_t st;
+    if ((st = ensure(ctx, ctx->d_colB, ctx->cap_colB, 3 * ps * sizeof(double)))) return st;
+    const int32_t init_status[2] = {0, INT_MAX};
+    HIP_TRY(hipMemcpyAsync(ctx->d_status, init_status, sizeof(init_status), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(ctx->d_nred, 0, 2 * sizeof(unsigned long long), s));
+    rpf_counters &c = ctx->counters;
+    c = rpf_counters{};
+    c.first_bad_pixel = -1;
+    float ms_filter = 0.f, ms_stats = 0.f;
+    if (timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
+    for (int i = 0; i < d->n_box; ++i) {
+        PassSetup ps_;
+        if ((st = setup_pass(ctx, d, d->box_sizes[i], d_planes, d_colour, ctx->d_colB, nullptr, ps_))) return st;
+        // rows outside the slab (halo) pass through unchanged
+        if (d->row_begin > 0 || d->row_end < d->H) HIP_TRY(launch_copy_f64(d_colour, ctx->d_colB, 3 * ps, s));
+        if (timing) HIP_TRY(hipEventRecord(ctx->ev[1], s));
+        HIP_TRY(launch_pixel_stats(ps_.p, s));
+        if (timing) HIP_TRY(hipEventRecord(ctx->ev[2], s));
+        HIP_TRY(launch_filter_pass(ps_.p, s, nullptr));
+        if (timing) {
+            HIP_TRY(hipEventRecord(ctx->ev[3], s));
+            HIP_TRY(hipEventSynchronize(ctx->ev[3]));
+            float a = 0.f, b = 0.f;
+            HIP_TRY(hipEventElapsedTime(&a, ctx->ev[1], ctx->ev[2]));
+            HIP_TRY(hipEventElapsedTime(&b, ctx->ev[2], ctx->ev[3]));
+            ms_stats += a;
+            ms_filter += b;
+        }
+        c.filter_kernel_launches++;
+        // filtered colours replace the film's colours (rpf.cpp:732)
+        HIP_TRY(hipMemcpyAsync(d_colour, ctx->d_colB, 3 * ps * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    if (timing) {
+        HIP_TRY(hipEventRecord(ctx->ev[3], s));
+        HIP_TRY(hipEventSynchronize(ctx->ev[3]));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[3]));
+        c.device_total_ms = t;
+    }
+    HIP_TRY(launch_nbhd_reduce(ctx->d_nbhd, d->W, d->row_begin, d->row_end, ctx->d_nred, s));
+    int32_t hst[2];
+    unsigned long long nred[2];
+    HIP_TRY(hipMemcpyAsync(hst, ctx->d_status, sizeof(hst), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(nred, ctx->d_nred, sizeof(nred), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c.samples_filtered = (int64_t)(d->row_end - d->row_begin) * d->W * d->S * d->n_box;
+    c.sum_nbhd = (int64_t)nred[0];
+    c.max_nbhd = (int32_t)nred[1];
+    c.nonfinite_pixels = hst[0];
+    c.first_bad_pixel = hst[0] ? hst[1] : -1;
+    c.filter_kernel_ms = ms_filter;
+    c.stats_kernel_ms = ms_stats;
+    if (hst[0] && d->degenerate_policy == RPF_DEGEN_REF_ABORT) {
+        char buf[160];
+        std::snprintf(buf, sizeof(buf), "non-finite filtered colour at pixel (x=%d, y=%d); %d pixel(s) affected "
+                      "(the reference exits here, rpf.cpp:702-705)", hst[1] % d->W, hst[1] / d->W, hst[0]);
+        return fail(ctx, RPF_E_NONFINITE, buf);
+    }
+    return RPF_OK;
+}
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rpf_version(void) { return "rpf_hip 0.1 (gfx950)"; }
+
+const char *rpf_status_string(int32_t s) {
+    switch (s) {
+    case RPF_OK: return "RPF_OK";
+    case RPF_E_BADARG: return "RPF_E_BADARG";
+    case RPF_E_HIP: return "RPF_E_HIP";
+    case RPF_E_NONFINITE: return "RPF_E_NONFINITE";
+    case RPF_E_NOMEM: return "RPF_E_NOMEM";
+    case RPF_E_UNSUPPORTED: return "RPF_E_UNSUPPORTED";
+    case RPF_E_NODEVICE: return "RPF_E_NODEVICE";
+    default: return "RPF_E_?";
+    }
+}
+
+int32_t rpf_create(rpf_ctx **out, int32_t device) {
+    if (!out) return RPF_E_BADARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RPF_E_NODEVICE;
+    if (device < 0 || device >= n) return RPF_E_BADARG;
+    rpf_ctx *ctx = new rpf_ctx();
+    ctx->device = device;
+    *out = ctx; // returned even on failure so that rpf_last_error() can be read; caller destroys it
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void **)&ctx->d_status, 2 * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->d_nred, 2 * sizeof(unsigned long long)));
+    for (auto &e : ctx->ev) HIP_TRY(hipEventCreate(&e));
+    return RPF_OK;
+}
+
+void rpf_destroy(rpf_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    void *bufs[] = {ctx->d_planes, ctx->d_rayw, ctx->d_colA, ctx->d_colB, ctx->d_pmean, ctx->d_pstd, ctx->d_nbhd,
+                    ctx->d_tlogt, ctx->d_srgb, ctx->d_prgb, ctx->d_status, ctx->d_nred};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    for (void *b : ctx->d_dbg)
+        if (b) (void)hipFree(b);
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *rpf_last_error(const rpf_ctx *ctx) { return ctx ? ctx->err.c_str() : "ctx is NULL"; }
+
+int64_t rpf_lds_bytes_required(int32_t S, int32_t box) {
+    if (S <= 0 || box <= 0) return -1;
+    const int64_t nmax = (int64_t)box * box * S;
+    if (nmax > 49 * 64) return -1;
+    const int nm = (int)nmax, pad = (nm + 15) / 16 * 16;
+    int bmax = (int)std::sqrt((double)nm);
+    if (bmax < 1) bmax = 1;
+    return lds_layout(S, nm, pad, bmax, (uint32_t)(nm + 1) * 8u <= 8192u).total;
+}
+
+int32_t rpf_colour_from_planes_device(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, double *d_colour,
+                                      void *stream) {
+    int32_t st = validate(ctx, d, false);
+    if (st) return st;
+    if (!d_planes || !d_colour) return fail(ctx, RPF_E_BADARG, "NULL device pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(launch_colour_from_planes(d_planes, d_colour, (uint64_t)d->W * d->H * d->S, s));
+    return RPF_OK;
+}
+
+int32_t rpf_reduce_device(rpf_ctx *ctx, const rpf_desc *d, const double *d_colour, const float *d_ray_weight,
+                          float *d_sample_rgb_out, float *d_pixel_rgb_out, void *stream) {
+    int32_t st = validate(ctx, d, false);
+    if (st) return st;
+    if (!d_colour) return fail(ctx, RPF_E_BADARG, "NULL device pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(launch_reduce(d_colour, d_ray_weight, d_sample_rgb_out, d_pixel_rgb_out, d->W, d->H, d->S, s));
+    return RPF_OK;
+}
+
+int32_t rpf_filter_device(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, double *d_colour, void *stream) {
+    int32_t st = validate(ctx, d, true);
+    if (st) return st;
+    if (!d_planes || !d_colour) return fail(ctx, RPF_E_BADARG, "NULL device pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    return run_passes(ctx, d, d_planes, d_colour, s);
+}
+
+int32_t rpf_filter(rpf_ctx *ctx, const rpf_desc *d, const float *planes, const float *ray_weight,
+                   float *sample_rgb_out, float *pixel_rgb_out) {
+    int32_t st = validate(ctx, d, true);
+    if (st) return st;
+    if (!planes) return fail(ctx, RPF_E_BADARG, "planes is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t ps = (size_t)d->W * d->H * d->S, HW = (size_t)d->W * d->H;
+    if ((st = ensure(ctx, ctx->d_planes, ctx->cap_planes, kNDim * ps * sizeof(float)))) return st;
+    if ((st = ensure(ctx, ctx->d_colA, ctx->cap_colA, 3 * ps * sizeof(double)))) return st;
+    if (ray_weight && (st = ensure(ctx, ctx->d_rayw, ctx->cap_rayw, ps * sizeof(float)))) return st;
+    if (sample_rgb_out && (st = ensure(ctx, ctx->d_srgb, ctx->cap_srgb, 3 * ps * sizeof(float)))) return st;
+    if (pixel_rgb_out && (st = ensure(ctx, ctx->d_prgb, ctx->cap_prgb, 3 * HW * sizeof(float)))) return st;
+    const double t0 = now_ms();
+    HIP_TRY(hipMemcpyAsync(ctx->d_planes, planes, kNDim * ps * sizeof(float), hipMemcpyHostToDevice, s));
+    if (ray_weight) HIP_TRY(hipMemcpyAsync(ctx->d_rayw, ray_weight, ps * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_colour_from_planes(ctx->d_planes, ctx->d_colA, ps, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const double t1 = now_ms();
+    const int32_t fst = run_passes(ctx, d, ctx->d_planes, ctx->d_colA, s);
+    if (fst != RPF_OK && fst != RPF_E_NONFINITE) return fst;
+    const double t2 = now_ms();
+    if (sample_rgb_out || pixel_rgb_out) {
+        HIP_TRY(launch_reduce(ctx->d_colA, ray_weight ? ctx->d_rayw : nullptr, sample_rgb_out ? ctx->d_srgb : nullptr,
+                              pixel_rgb_out ? ctx->d_prgb : nullptr, d->W, d->H, d->S, s));
+        if (sample_rgb_out)
+            HIP_TRY(hipMemcpyAsync(sample_rgb_out, ctx->d_srgb, 3 * ps * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (pixel_rgb_out)
+            HIP_TRY(hipMemcpyAsync(pixel_rgb_out, ctx->d_prgb, 3 * HW * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    ctx->counters.h2d_ms = (float)(t1 - t0);
+    ctx->counters.d2h_ms = (float)(now_ms() - t2);
+    return fst;
+}
+
+int32_t rpf_stage_pixel_stats(rpf_ctx *ctx, const rpf_desc *d, const float *planes, double *mean, double *stddev) {
+    int32_t st = validate(ctx, d, false);
+    if (st) return st;
+    if (!planes || !mean || !stddev) return fail(ctx, RPF_E_BADARG, "NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t ps = (size_t)d->W * d->H * d->S, HW = (size_t)d->W * d->H;
+    if ((st = ensure(ctx, ctx->d_planes, ctx->cap_planes, kNDim * ps * sizeof(float)))) return st;
+    if ((st = ensure(ctx, ctx->d_pmean, ctx->cap_pmean, HW * kNFeat * sizeof(double)))) return st;
+    if ((st = ensure(ctx, ctx->d_pstd, ctx->cap_pstd, HW * kNFeat * sizeof(double)))) return st;
+    HIP_TRY(hipMemcpyAsync(ctx->d_planes, planes, kNDim * ps * sizeof(float), hipMemcpyHostToDevice, s));
+    PassParams p{};
+    p.W = d->W; p.H = d->H; p.S = d->S; p.policy = d->degenerate_policy;
+    p.plane_stride = ps; p.planes = ctx->d_planes; p.pmean = ctx->d_pmean; p.pstd = ctx->d_pstd;
+    HIP_TRY(launch_pixel_stats(p, s));
+    std::vector<double> m(HW * kNFeat), sd(HW * kNFeat);
+    HIP_TRY(hipMemcpyAsync(m.data(), ctx->d_pmean, m.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(sd.data(), ctx->d_pstd, sd.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t pix = 0; pix < HW; ++pix) // device planes are [12][H*W]; the ABI is pixel-major
+        for (int k = 0; k < kNFeat; ++k) {
+            mean[pix * kNFeat + k] = m[(size_t)k * HW + pix];
+            stddev[pix * kNFeat + k] = sd[(size_t)k * HW + pix];
+        }
+    return RPF_OK;
+}
+
+int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *d, int32_t box, const float *planes,
+                              const double *colour_in, double *colour_out, const rpf_debug *dbg) {
+    int32_t st = validate(ctx, d, false);
+    if (st) return st;
+    if (!planes || !colour_out) return fail(ctx, RPF_E_BADARG, "NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t ps = (size_t)d->W * d->H * d->S, HW = (size_t)d->W * d->H;
+    if ((st = ensure(ctx, ctx->d_planes, ctx->cap_planes, kNDim * ps * sizeof(float)))) return st;
+    if ((st = ensure(ctx, ctx->d_colA, ctx->cap_colA, 3 * ps * sizeof(double)))) return st;
+    if ((st = ensure(ctx, ctx->d_colB, ctx->cap_colB, 3 * ps * sizeof(double)))) return st;
+    HIP_TRY(hipMemcpyAsync(ctx->d_planes, planes, kNDim * ps * sizeof(float), hipMemcpyHostToDevice, s));
+    if (colour_in)
+        HIP_TRY(hipMemcpyAsync(ctx->d_colA, colour_in, 3 * ps * sizeof(double), hipMemcpyHostToDevice, s));
+    else
+        HIP_TRY(launch_colour_from_planes(ctx->d_planes, ctx->d_colA, ps, s));
+    // debug planes
+    const size_t dbg_bytes[9] = {HW * 4, HW * kNDim * 8, HW * kNDim * 8, HW * kNPair * 8, HW * 3 * 8,
+                                 HW * kNFeat * 8, HW * 8, HW * kNDim * 4, HW * 4};
+    void *host_dbg[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (dbg) {
+        void *tmp[9] = {dbg->nbhd_size, dbg->mean, dbg->stddev, dbg->mi, dbg->alpha, dbg->beta, dbg->wrc,
+                        dbg->bin_hash, dbg->member_hash};
+        std::memcpy(host_dbg, tmp, sizeof(tmp));
+    }
+    rpf_debug dev{};
+    void **dev_slots[9] = {(void **)&dev.nbhd_size, (void **)&dev.mean, (void **)&dev.stddev, (void **)&dev.mi,
+                           (void **)&dev.alpha, (void **)&dev.beta, (void **)&dev.wrc, (void **)&dev.bin_hash,
+                           (void **)&dev.member_hash};
+    for (int i = 0; i < 9; ++i) {
+        if (!host_dbg[i]) continue;
+        if ((st = ensure(ctx, ctx->d_dbg[i], ctx->cap_dbg[i], dbg_bytes[i]))) return st;
+        HIP_TRY(hipMemsetAsync(ctx->d_dbg[i], 0, dbg_bytes[i], s));
+        *dev_slots[i] = ctx->d_dbg[i];
+    }
+    const int32_t init_status[2] = {0, INT_MAX};
+    HIP_TRY(hipMemcpyAsync(ctx->d_status, init_status, sizeof(init_status), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(ctx->d_nred, 0, 2 * sizeof(unsigned long long), s));
+    PassSetup ps_;
+    if ((st = setup_pass(ctx, d, box, ctx->d_planes, ctx->d_colA, ctx->d_colB, &dev, ps_))) return st;
+    HIP_TRY(launch_copy_f64(ctx->d_colA, ctx->d_colB, 3 * ps, s));
+    const bool timing = (d->flags & RPF_FLAG_TIMING) != 0;
+    HIP_TRY(launch_pixel_stats(ps_.p, s));
+    if (timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
+    HIP_TRY(launch_filter_pass(ps_.p, s, nullptr));
+    if (timing) HIP_TRY(hipEventRecord(ctx->ev[1], s));
+    HIP_TRY(launch_nbhd_reduce(ctx->d_nbhd, d->W, d->row_begin, d->row_end, ctx->d_nred, s));
+    HIP_TRY(hipMemcpyAsync(colour_out, ctx->d_colB, 3 * ps * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (dbg && dbg->nbhd_size) // N is always produced in the context's own plane
+        HIP_TRY(hipMemcpyAsync(ctx->d_dbg[0], ctx->d_nbhd, HW * 4, hipMemcpyDeviceToDevice, s));
+    for (int i = 0; i < 9; ++i)
+        if (host_dbg[i]) HIP_TRY(hipMemcpyAsync(host_dbg[i], ctx->d_dbg[i], dbg_bytes[i], hipMemcpyDeviceToHost, s));
+    int32_t hst[2];
+    unsigned long long nred[2];
+    HIP_TRY(hipMemcpyAsync(hst, ctx->d_status, sizeof(hst), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(nred, ctx->d_nred, sizeof(nred), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    rpf_counters &c = ctx->counters;
+    c = rpf_counters{};
+    c.samples_filtered = (int64_t)(d->row_end - d->row_begin) * d->W * d->S;
+    c.sum_nbhd = (int64_t)nred[0];
+    c.max_nbhd = (int32_t)nred[1];
+    c.nonfinite_pixels = hst[0];
+    c.first_bad_pixel = hst[0] ? hst[1] : -1;
+    c.filter_kernel_launches = 1;
+    if (timing) HIP_TRY(hipEventElapsedTime(&c.filter_kernel_ms, ctx->ev[0], ctx->ev[1]));
+    if (hst[0] && d->degenerate_policy == RPF_DEGEN_REF_ABORT)
+        return fail(ctx, RPF_E_NONFINITE, "non-finite filtered colour (the reference exits here, rpf.cpp:702-705)");
+    return RPF_OK;
+}
+
+int32_t rpf_query_counters(rpf_ctx *ctx, rpf_counters *out) {
+    if (!ctx || !out) return RPF_E_BADARG;
+    *out = ctx->counters;
+    return RPF_OK;
+}
+
+} // extern "C"

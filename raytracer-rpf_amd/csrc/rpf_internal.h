@@ -1,0 +1,54 @@
+// rpf_internal.h -- shared between the kernel TU (rpf_kernels.hip) and the C-ABI TU (rpf_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rpf_hip.h"
+
+namespace rpf {
+
+constexpr int kNDim = RPF_NDIM;   // 19
+constexpr int kNFeat = RPF_NFEAT; // 12
+constexpr int kNPair = RPF_NPAIR; // 96
+constexpr int kColP = 0, kColC = 2, kColR = 5, kColF = 7;
+constexpr int kWave = 64;
+constexpr int kStageChunk = 32; // samples staged per step of the in-order (reference-order) sums
+
+// everything one pass needs, passed by value to the kernels
+struct PassParams {
+    int32_t W, H, S;
+    int32_t row_begin, row_end;
+    int32_t box, b;        // b = (box-1)/2, rpf.cpp:561
+    int32_t beta_map, policy;
+    int32_t nmax;          // box*box*S: capacity of a neighbourhood
+    int32_t nmax_pad;      // nmax rounded up to 16 (bin-id rows)
+    int32_t bmax;          // floor(sqrt(nmax)): max histogram bins per axis
+    double eps, seed, sigma_p;
+    uint64_t plane_stride; // H*W*S
+    const float *planes;   // 19 fp32 planes (colour planes unused)
+    const double *col_in;  // 3 fp64 planes
+    double *col_out;       // 3 fp64 planes
+    const double *pmean;   // [12][H*W] stage 1a
+    const double *pstd;    // [12][H*W]
+    const double *tlogt;   // T[k] = k ln k, k = 0..nmax
+    int32_t *nbhd;         // [H*W] N per pixel (always written)
+    int32_t *status;       // [0] count of NaN pixels, [1] lowest bad pixel index (atomicMin)
+    rpf_debug dbg;         // device pointers, any may be null
+};
+
+struct LdsLayout {
+    uint32_t off_T, off_stat, off_hx, off_mi, off_own, off_off, off_union, off_hist, total;
+};
+LdsLayout lds_layout(int S, int nmax, int nmax_pad, int bmax, bool t_in_lds);
+
+hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s);
+hipError_t launch_filter_pass(const PassParams &p, hipStream_t s, uint32_t *lds_bytes_out);
+hipError_t launch_colour_from_planes(const float *planes, double *colour, uint64_t plane_stride, hipStream_t s);
+hipError_t launch_copy_f64(const double *src, double *dst, uint64_t n, hipStream_t s);
+hipError_t launch_reduce(const double *colour, const float *ray_weight, float *sample_rgb, float *pixel_rgb, int W,
+                         int H, int S, hipStream_t s);
+hipError_t launch_nbhd_reduce(const int32_t *nbhd, int W, int row_begin, int row_end, unsigned long long *out2,
+                              hipStream_t s);
+int max_lds_per_block();
+
+} // namespace rpf

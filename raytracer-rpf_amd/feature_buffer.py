@@ -1,0 +1,202 @@
+"""Per-sample feature buffers: layout helpers and the seeded synthetic generator.
+
+Layout (host and HBM, identical): 19 SoA planes of fp32, plane ``d`` holds ``[y][x][s]``; the dims are
+the reference's ``SampleData`` vector (/root/reference/src/custom/sd.h:62-94):
+
+    0,1 pFilm | 2,3,4 L rgb | 5,6 pLens (random parameters) | 7..9 n0 | 10..12 p0 | 13..15 n1 | 16..18 p1
+
+The reference container is ``samples[x][y][s]`` of 19 doubles (sample_film.cpp:32-42); values are
+fp32-valued because pbrt's ``Float`` is ``float`` (core/pbrt.h), so fp32 planes hold them exactly.
+
+The generator is counter-based (a 32-bit integer hash of (seed, stream, global sample index)), written
+against a tiny array-backend shim so the SAME code runs on numpy (tests, here) and on torch tensors on
+the GPU (bench, where 1080p..4K buffers are produced directly in HBM).  Pixel statistics do not depend
+on the image size or on which row slab a rank generates (absolute pixel coordinates are used), which is
+what makes the multi-GPU weak-scaling workload well defined.
+"""
+import math
+
+import numpy as np
+
+NDIM = 19
+P0, C0, R0, F0 = 0, 2, 5, 7  # column groups
+
+
+class _NP:
+    """numpy backend shim"""
+    i64 = np.int64
+    f32 = np.float32
+    f64 = np.float64
+
+    @staticmethod
+    def arange(n):
+        return np.arange(n, dtype=np.int64)
+
+    floor, sqrt, log, cos, sin, where, stack = np.floor, np.sqrt, np.log, np.cos, np.sin, np.where, np.stack
+
+    @staticmethod
+    def cast(a, dt):
+        return a.astype(dt)
+
+
+class _TORCH:
+    """torch backend shim (device chosen at construction)"""
+
+    def __init__(self, device):
+        import torch
+        self.t = torch
+        self.device = device
+        self.i64, self.f32, self.f64 = torch.int64, torch.float32, torch.float64
+        self.floor, self.sqrt, self.log, self.cos, self.sin, self.where = (
+            torch.floor, torch.sqrt, torch.log, torch.cos, torch.sin, torch.where)
+
+    def arange(self, n):
+        return self.t.arange(n, dtype=self.t.int64, device=self.device)
+
+    def stack(self, xs, axis=0):
+        return self.t.stack(xs, dim=axis)
+
+    @staticmethod
+    def cast(a, dt):
+        return a.to(dt)
+
+
+_M32 = 0xFFFFFFFF
+
+
+def _hash32(xp, x):
+    """lowbias32 integer hash evaluated in int64 lanes (identical on numpy and torch)."""
+    x = x & _M32
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & _M32
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & _M32
+    x = x ^ (x >> 16)
+    return x
+
+
+def _uniform(xp, idx, seed, stream):
+    """U[0,1) with 24 random bits (exact in fp32) for global sample index ``idx``."""
+    h = _hash32(xp, idx ^ ((seed * 0x9E3779B1 + stream * 0x85EBCA6B) & _M32))
+    h = _hash32(xp, h + (idx >> 32) + stream)
+    return xp.cast(h >> 8, xp.f64) * (1.0 / 16777216.0)
+
+
+def _gauss(xp, idx, seed, stream):
+    u1 = _uniform(xp, idx, seed, stream)
+    u2 = _uniform(xp, idx, seed, stream + 101)
+    return xp.sqrt(-2.0 * xp.log(u1 + 1.0 / 33554432.0)) * xp.cos(2.0 * math.pi * u2)
+
+
+def synth_planes(W, H, S, seed=20250103, sigma_f=0.05, sigma_c=1e-4, row0=0, xp=None, lens_colour=True,
+                 mode="smooth"):
+    """Synthetic feature buffer, planes [19, H, W, S] fp32 (SURVEY.md section 8d recipe).
+
+    ``row0`` is the image row of buffer row 0 (slab generation: a rank owning rows [a,b) of a taller image
+    passes row0=a and H=b-a and gets exactly the rows the single-buffer call would produce).
+    mode="smooth": first-hit features smooth in pFilm + Gaussian jitter sigma_f, second-hit features
+    continuous functions of the random parameters.  Large neighbourhoods, near-identity filter output
+    (the reference's sigma^2 = 0.002^2/(1-W_r_c)^2 kills every cross weight on generic data):
+    the throughput workload.
+    mode="clustered": every feature is a per-sample MODE (chosen by which half of the lens square the
+    random parameters fall in: a defocus / two-surface edge inside every pixel) plus jitter sigma_f, and
+    the colour is a mode value plus noise sigma_c.  Same-mode samples are near-identical in normalised
+    space, so the cross-bilateral weights are non-trivial and the filter measurably changes the colours:
+    the parity-fixture workload.
+    """
+    xp = xp or _NP
+    n = H * W * S
+    lin = xp.arange(n)
+    s = lin % S
+    px = (lin // S) % W
+    py = (lin // (S * W)) + row0
+    gidx = (py * W + px) * S + s  # global sample index: slab independent
+
+    def U(k):
+        return _uniform(xp, gidx, seed, k)
+
+    def G(k):
+        return _gauss(xp, gidx, seed, k)
+
+    u1, u2, r1, r2 = U(1), U(2), U(3), U(4)
+    fx = xp.cast(px, xp.f64) + u1
+    fy = xp.cast(py, xp.f64) + u2
+    X, Y = fx * 0.01, fy * 0.01
+
+    # first-hit features: smooth in pFilm + Gaussian jitter
+    nx = 0.35 * xp.sin(3.0 * X) + sigma_f * G(10)
+    ny = 0.35 * xp.cos(2.0 * Y) + sigma_f * G(11)
+    nz = xp.sqrt(1.0 - 0.35 * 0.35 * 2.0 * 0.5) + 0.05 * xp.sin(X + Y) + sigma_f * G(12)
+    step = xp.cast((xp.cast(xp.floor(fx / 256.0), xp.i64) % 2), xp.f64)
+    p0x = 0.01 * fx + sigma_f * G(13)
+    p0y = 0.01 * fy + sigma_f * G(14)
+    p0z = 0.05 * xp.sin(3.0 * X) + 2.0 * step + sigma_f * G(15)
+    # second-hit features: functions of the random parameters
+    th = 2.0 * math.pi * r1
+    cz = 2.0 * r2 - 1.0
+    sr = xp.sqrt(1.0 - cz * cz + 1e-12)
+    n1x = sr * xp.cos(th) + sigma_f * G(16)
+    n1y = sr * xp.sin(th) + sigma_f * G(17)
+    n1z = cz + sigma_f * G(18)
+    p1x = p0x + 2.0 * n1x + sigma_f * G(19)
+    p1y = p0y + 2.0 * n1y + sigma_f * G(20)
+    p1z = p0z + 2.0 * n1z + sigma_f * G(21)
+    # colour: region albedo x lens-dependent visibility x slow shading + jitter
+    region = xp.cast(xp.cast(xp.floor(fx / 64.0), xp.i64) + xp.cast(xp.floor(fy / 64.0), xp.i64), xp.i64) % 3
+    shade = 0.75 + 0.25 * xp.sin(X * 2.0) * xp.cos(Y * 2.0)
+    if lens_colour:
+        vis = xp.where(r1 < 0.5, 1.0 + 0.0 * r1, 0.15 + 0.0 * r1)
+    else:
+        vis = 1.0 + 0.0 * r1
+    alb = [0.8 - 0.25 * xp.cast(region == k, xp.f64) for k in range(3)]
+    cr = alb[0] * vis * shade + sigma_c * G(30)
+    cg = alb[1] * vis * shade + sigma_c * G(31)
+    cb = alb[2] * vis * shade + sigma_c * G(32)
+
+    if mode == "clustered":
+        ma = xp.cast(r2 < 0.5, xp.f64)  # first-hit mode (foreground / background through the lens)
+        mb = xp.cast(r1 < 0.5, xp.f64)  # second-hit mode
+        slow = 0.02 * xp.sin(X * 2.0 + Y)
+        nx = 0.6 * ma - 0.3 + slow + sigma_f * G(10)
+        ny = 0.5 - 0.7 * ma + slow + sigma_f * G(11)
+        nz = 0.8 - 0.2 * ma + slow + sigma_f * G(12)
+        p0x = 0.002 * fx + 1.5 * ma + sigma_f * G(13)
+        p0y = 0.002 * fy - 0.8 * ma + sigma_f * G(14)
+        p0z = 3.0 * ma + slow + sigma_f * G(15)
+        n1x = 0.7 * mb - 0.2 + slow + sigma_f * G(16)
+        n1y = 0.1 + 0.5 * mb + slow + sigma_f * G(17)
+        n1z = 0.9 - 0.6 * mb + slow + sigma_f * G(18)
+        p1x = p0x + 2.0 * mb + sigma_f * G(19)
+        p1y = p0y - 1.0 * mb + sigma_f * G(20)
+        p1z = p0z + 0.5 * mb + sigma_f * G(21)
+        vis = 0.15 + 0.85 * mb
+        cr = alb[0] * vis * shade + sigma_c * G(30)
+        cg = alb[1] * vis * shade + sigma_c * G(31)
+        cb = alb[2] * vis * shade + sigma_c * G(32)
+    elif mode != "smooth":
+        raise ValueError("mode must be 'smooth' or 'clustered'")
+
+    cols = [fx, fy, cr, cg, cb, r1, r2, nx, ny, nz, p0x, p0y, p0z, n1x, n1y, n1z, p1x, p1y, p1z]
+    planes = xp.stack([xp.cast(c, xp.f32) for c in cols], 0)
+    return planes.reshape(NDIM, H, W, S)
+
+
+def torch_backend(device):
+    return _TORCH(device)
+
+
+# ---- AoS <-> SoA (the reference container order is samples[x][y][s][19] doubles) -------------------
+def aos_to_planes(aos):
+    """aos: float64 [W][H][S][19] (SamplingFilm order, sample_film.cpp:32-42) -> planes f32 [19,H,W,S]."""
+    aos = np.asarray(aos)
+    return np.ascontiguousarray(np.transpose(aos, (3, 1, 0, 2)).astype(np.float32))
+
+
+def planes_to_aos(planes):
+    planes = np.asarray(planes)
+    return np.ascontiguousarray(np.transpose(planes, (2, 1, 3, 0)).astype(np.float64))
+
+
+def halo_rows(box):
+    """rows of neighbouring slabs a row-tiled rank needs (rpf.cpp:561: b = (box-1)/2)."""
+    return (box - 1) // 2

@@ -1,0 +1,19 @@
+"""Loader for the product package: the directory is named ``raytracer-rpf_amd`` (not a valid Python
+identifier), so it is registered under the import name ``raytracer_rpf_amd``."""
+import importlib.util
+import os
+import sys
+
+_NAME = "raytracer_rpf_amd"
+
+
+def load():
+    if _NAME in sys.modules:
+        return sys.modules[_NAME]
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "raytracer-rpf_amd")
+    spec = importlib.util.spec_from_file_location(_NAME, os.path.join(root, "__init__.py"),
+                                                  submodule_search_locations=[root])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[_NAME] = mod
+    spec.loader.exec_module(mod)
+    return mod
