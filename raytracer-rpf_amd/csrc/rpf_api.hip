@@ -8,6 +8,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -28,7 +29,8 @@ struct rpf_ctx {
     double *d_pmean = nullptr;   size_t cap_pmean = 0;    // [12][H*W]
     double *d_pstd = nullptr;    size_t cap_pstd = 0;
     int32_t *d_nbhd = nullptr;   size_t cap_nbhd = 0;
-    double *d_tlogt = nullptr;   size_t cap_tlogt = 0;    int tlogt_n = 0;
+    uint64_t *d_tfix = nullptr;  size_t cap_tfix = 0;     int tfix_n = 0;     // round(k ln k * 2^44), k = 0..n
+    uint64_t *d_dfix = nullptr;  size_t cap_dfix = 0;                         // first differences
     float *d_srgb = nullptr;     size_t cap_srgb = 0;
     float *d_prgb = nullptr;     size_t cap_prgb = 0;
     int32_t *d_status = nullptr;                           // [0] bad count [1] first bad
@@ -86,15 +88,19 @@ int32_t validate(rpf_ctx *ctx, const rpf_desc *d, bool need_boxes) {
     return RPF_OK;
 }
 
-int32_t ensure_tlogt(rpf_ctx *ctx, int nmax) {
-    if (ctx->d_tlogt && ctx->tlogt_n >= nmax + 1) return RPF_OK;
-    std::vector<double> t((size_t)nmax + 1);
-    t[0] = 0.0;
-    for (int k = 1; k <= nmax; ++k) t[k] = (double)k * std::log((double)k);
-    int32_t st = ensure(ctx, ctx->d_tlogt, ctx->cap_tlogt, t.size() * sizeof(double));
-    if (st) return st;
-    HIP_TRY(hipMemcpy(ctx->d_tlogt, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
-    ctx->tlogt_n = nmax + 1;
+// T[k] = k ln k in 2^-44 fixed point (computed in long double, rounded once) and its first differences
+int32_t ensure_tables(rpf_ctx *ctx, int nmax) {
+    if (ctx->d_tfix && ctx->tfix_n >= nmax + 1) return RPF_OK;
+    std::vector<uint64_t> t((size_t)nmax + 1), d((size_t)nmax + 1, 0);
+    t[0] = 0;
+    for (int k = 1; k <= nmax; ++k) t[k] = (uint64_t)std::llroundl(std::ldexp((long double)k * std::log((long double)k), 44));
+    for (int k = 0; k < nmax; ++k) d[k] = t[k + 1] - t[k];
+    int32_t st;
+    if ((st = ensure(ctx, ctx->d_tfix, ctx->cap_tfix, t.size() * sizeof(uint64_t)))) return st;
+    if ((st = ensure(ctx, ctx->d_dfix, ctx->cap_dfix, d.size() * sizeof(uint64_t)))) return st;
+    HIP_TRY(hipMemcpy(ctx->d_tfix, t.data(), t.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_dfix, d.data(), d.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    ctx->tfix_n = nmax + 1;
     return RPF_OK;
 }
 
@@ -112,10 +118,13 @@ int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const float *d_plan
     p.row_begin = d->row_begin; p.row_end = d->row_end;
     p.box = box; p.b = (box - 1) / 2;
     p.beta_map = d->beta_map; p.policy = d->degenerate_policy;
+    {
+        const char *sm = std::getenv("RPF_STAGE_MASK"); // timing ablation knob for profiling; results are wrong when set
+        p.stage_mask = sm ? std::atoi(sm) : -1;
+    }
     const int64_t nmax64 = (int64_t)box * box * d->S;
     if (nmax64 > 49 * 64) return fail(ctx, RPF_E_UNSUPPORTED, "box*box*S > 3136: neighbourhood too large for the wave-per-pixel kernel");
     p.nmax = (int)nmax64;
-    p.nmax_pad = (p.nmax + 15) / 16 * 16;
     p.bmax = (int)std::sqrt((double)p.nmax);
     if (p.bmax < 1) p.bmax = 1;
     p.eps = d->eps; p.seed = d->sigma_seed;
@@ -127,12 +136,11 @@ int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const float *d_plan
     if ((st = ensure(ctx, ctx->d_pmean, ctx->cap_pmean, HW * kNFeat * sizeof(double)))) return st;
     if ((st = ensure(ctx, ctx->d_pstd, ctx->cap_pstd, HW * kNFeat * sizeof(double)))) return st;
     if ((st = ensure(ctx, ctx->d_nbhd, ctx->cap_nbhd, HW * sizeof(int32_t)))) return st;
-    if ((st = ensure_tlogt(ctx, p.nmax))) return st;
-    p.pmean = ctx->d_pmean; p.pstd = ctx->d_pstd; p.tlogt = ctx->d_tlogt;
+    if ((st = ensure_tables(ctx, p.nmax))) return st;
+    p.pmean = ctx->d_pmean; p.pstd = ctx->d_pstd; p.tfix = ctx->d_tfix; p.dfix = ctx->d_dfix;
     p.nbhd = ctx->d_nbhd; p.status = ctx->d_status;
     if (dbg_dev) p.dbg = *dbg_dev;
-    const bool t_in_lds = (uint32_t)(p.nmax + 1) * 8u <= 8192u;
-    out.lds = lds_layout(p.S, p.nmax, p.nmax_pad, p.bmax, t_in_lds).total;
+    out.lds = lds_layout(p.S, p.nmax, p.bmax, table_in_lds(p.nmax)).total;
     if ((int)out.lds > max_lds_per_block())
         return fail(ctx, RPF_E_UNSUPPORTED, "neighbourhood working set exceeds 160 KiB of LDS");
     return RPF_OK;
@@ -249,7 +257,7 @@ void rpf_destroy(rpf_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *bufs[] = {ctx->d_planes, ctx->d_rayw, ctx->d_colA, ctx->d_colB, ctx->d_pmean, ctx->d_pstd, ctx->d_nbhd,
-                    ctx->d_tlogt, ctx->d_srgb, ctx->d_prgb, ctx->d_status, ctx->d_nred};
+                    ctx->d_tfix, ctx->d_dfix, ctx->d_srgb, ctx->d_prgb, ctx->d_status, ctx->d_nred};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (void *b : ctx->d_dbg)
@@ -266,10 +274,10 @@ int64_t rpf_lds_bytes_required(int32_t S, int32_t box) {
     if (S <= 0 || box <= 0) return -1;
     const int64_t nmax = (int64_t)box * box * S;
     if (nmax > 49 * 64) return -1;
-    const int nm = (int)nmax, pad = (nm + 15) / 16 * 16;
+    const int nm = (int)nmax;
     int bmax = (int)std::sqrt((double)nm);
     if (bmax < 1) bmax = 1;
-    return lds_layout(S, nm, pad, bmax, (uint32_t)(nm + 1) * 8u <= 8192u).total;
+    return lds_layout(S, nm, bmax, table_in_lds(nm)).total;
 }
 
 int32_t rpf_colour_from_planes_device(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, double *d_colour,

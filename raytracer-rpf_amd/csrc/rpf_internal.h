@@ -20,8 +20,8 @@ struct PassParams {
     int32_t row_begin, row_end;
     int32_t box, b;        // b = (box-1)/2, rpf.cpp:561
     int32_t beta_map, policy;
+    int32_t stage_mask;    // diagnostics only (env RPF_STAGE_MASK): bit0 stats chain, bit1 bins, bit2 MI, bit3 weights; -1 = all
     int32_t nmax;          // box*box*S: capacity of a neighbourhood
-    int32_t nmax_pad;      // nmax rounded up to 16 (bin-id rows)
     int32_t bmax;          // floor(sqrt(nmax)): max histogram bins per axis
     double eps, seed, sigma_p;
     uint64_t plane_stride; // H*W*S
@@ -30,16 +30,19 @@ struct PassParams {
     double *col_out;       // 3 fp64 planes
     const double *pmean;   // [12][H*W] stage 1a
     const double *pstd;    // [12][H*W]
-    const double *tlogt;   // T[k] = k ln k, k = 0..nmax
+    const uint64_t *tfix;  // round(k ln k * 2^44), k = 0..nmax
+    const uint64_t *dfix;  // tfix[k+1] - tfix[k], k = 0..nmax-1
     int32_t *nbhd;         // [H*W] N per pixel (always written)
     int32_t *status;       // [0] count of NaN pixels, [1] lowest bad pixel index (atomicMin)
     rpf_debug dbg;         // device pointers, any may be null
 };
 
 struct LdsLayout {
-    uint32_t off_T, off_stat, off_hx, off_mi, off_own, off_off, off_union, off_hist, total;
+    uint32_t off_T, off_stat, off_hx, off_pair, off_mi, off_own, off_off, off_union, off_hist, total;
 };
-LdsLayout lds_layout(int S, int nmax, int nmax_pad, int bmax, bool t_in_lds);
+LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds);
+int samples_per_lane(int nmax); // the K the filter kernel is instantiated with (0 = unsupported)
+bool table_in_lds(int nmax);
 
 hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s);
 hipError_t launch_filter_pass(const PassParams &p, hipStream_t s, uint32_t *lds_bytes_out);

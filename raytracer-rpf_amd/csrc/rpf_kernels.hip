@@ -30,6 +30,8 @@ namespace rpf {
 
 namespace {
 
+constexpr int kTFixBits = 44; // T[k] = k ln k is tabulated as round(T * 2^44): exact integer sums, |T| < 2^15 * 2^44
+
 // MI pair table in ComputeCFWeights call order (rpf.cpp:416-442)
 struct PairTable {
     unsigned char a[kNPair], b[kNPair];
@@ -80,6 +82,87 @@ __device__ __forceinline__ uint32_t fnv1a_u16(uint32_t h, uint32_t v) {
     return h;
 }
 
+// KW consecutive 32-bit words per lane, as one wide LDS access where the width allows
+template <int KW>
+__device__ __forceinline__ void load_words(const uint32_t *src, uint32_t (&w)[KW]) {
+    if constexpr (KW % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < KW / 4; ++i) {
+            const uint4 v = reinterpret_cast<const uint4 *>(src)[i];
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+    } else if constexpr (KW % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < KW / 2; ++i) {
+            const uint2 v = reinterpret_cast<const uint2 *>(src)[i];
+            w[2 * i] = v.x; w[2 * i + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < KW; ++i) w[i] = src[i];
+    }
+}
+template <int KW>
+__device__ __forceinline__ void store_words(uint32_t *dst, const uint32_t (&w)[KW]) {
+    if constexpr (KW % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < KW / 4; ++i) reinterpret_cast<uint4 *>(dst)[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+    } else if constexpr (KW % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < KW / 2; ++i) reinterpret_cast<uint2 *>(dst)[i] = make_uint2(w[2 * i], w[2 * i + 1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < KW; ++i) dst[i] = w[i];
+    }
+}
+
+// clear `cells` 32-bit histogram cells (buffer is 16-byte aligned and padded to a multiple of 4 cells)
+__device__ __forceinline__ void zero_words(uint32_t *h, int cells, int lane) {
+    for (int t = lane * 4; t < cells; t += kWave * 4) *reinterpret_cast<uint4 *>(h + t) = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// Sum 16 per-lane accumulators over the 64 lanes with a transposed butterfly (17 exchanges instead of
+// 16 x 6): afterwards every lane holds the wave total of accumulator reduce16_slot(lane).
+__device__ __forceinline__ int reduce16_slot(int lane) {
+    return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+}
+__device__ __forceinline__ uint64_t reduce16(const uint64_t (&a)[16], int lane) {
+    uint64_t b8[8], b4[4], b2[2];
+    {
+        const bool up = (lane & 32) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint64_t keep = up ? a[i + 8] : a[i], send = up ? a[i] : a[i + 8];
+            b8[i] = keep + (uint64_t)__shfl_xor((unsigned long long)send, 32, 64);
+        }
+    }
+    {
+        const bool up = (lane & 16) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint64_t keep = up ? b8[i + 4] : b8[i], send = up ? b8[i] : b8[i + 4];
+            b4[i] = keep + (uint64_t)__shfl_xor((unsigned long long)send, 16, 64);
+        }
+    }
+    {
+        const bool up = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint64_t keep = up ? b4[i + 2] : b4[i], send = up ? b4[i] : b4[i + 2];
+            b2[i] = keep + (uint64_t)__shfl_xor((unsigned long long)send, 8, 64);
+        }
+    }
+    uint64_t v;
+    {
+        const bool up = (lane & 4) != 0;
+        const uint64_t keep = up ? b2[1] : b2[0], send = up ? b2[0] : b2[1];
+        v = keep + (uint64_t)__shfl_xor((unsigned long long)send, 4, 64);
+    }
+    v += (uint64_t)__shfl_xor((unsigned long long)v, 2, 64);
+    v += (uint64_t)__shfl_xor((unsigned long long)v, 1, 64);
+    return v;
+}
+
 // value of column c of the sample at plane offset `off`: colours come from the fp64 colour planes
 __device__ __forceinline__ double load_col(const PassParams &p, int c, uint32_t off) {
     if (c >= kColC && c < kColC + 3) return p.col_in[(uint64_t)(c - kColC) * p.plane_stride + off];
@@ -120,14 +203,16 @@ __global__ __launch_bounds__(256) void pixel_stats_kernel(PassParams p) {
 template <int K, bool T_IN_LDS>
 __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayout L) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double *sT = reinterpret_cast<double *>(smem + L.off_T);
+    constexpr int KW = (K + 3) / 4; // 32-bit words of bin ids per lane and column
+    uint64_t *sD = reinterpret_cast<uint64_t *>(smem + L.off_T); // D[c] = T[c+1]-T[c], 2^-44 fixed point
     double *sStat = reinterpret_cast<double *>(smem + L.off_stat); // M[19], SD[19]
-    double *sHX = reinterpret_cast<double *>(smem + L.off_hx);     // sum_i T[hx_i] per column
+    uint64_t *sHXf = reinterpret_cast<uint64_t *>(smem + L.off_hx);     // sum_i T[hx_i] per column (fixed point)
+    uint64_t *sPairF = reinterpret_cast<uint64_t *>(smem + L.off_pair); // sum_ij T[J_ij] per pair (fixed point)
     double *sMI = reinterpret_cast<double *>(smem + L.off_mi);     // 96 MI values
     double *sOwn = reinterpret_cast<double *>(smem + L.off_own);   // raw own samples [S][19]
     uint32_t *sOff = reinterpret_cast<uint32_t *>(smem + L.off_off);
     double *sStage = reinterpret_cast<double *>(smem + L.off_union); // [19][kStageChunk+1] (aliases bins)
-    uint8_t *sBins = smem + L.off_union;                             // [19][nmax_pad]
+    uint32_t *sBinW = reinterpret_cast<uint32_t *>(smem + L.off_union); // bin ids [19][64][KW] words
     uint32_t *sHist = reinterpret_cast<uint32_t *>(smem + L.off_hist);
 
     const int lane = threadIdx.x;
@@ -144,10 +229,10 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
     const uint64_t HW = (uint64_t)H * W;
     const uint64_t pix = (uint64_t)y * W + x;
 
-    auto Tl = [&](uint32_t k) -> double { return T_IN_LDS ? sT[k] : p.tlogt[k]; };
+    auto Dl = [&](uint32_t k) -> uint64_t { return T_IN_LDS ? sD[k] : p.dfix[k]; };
 
     if (T_IN_LDS)
-        for (int k = lane; k <= p.nmax; k += kWave) sT[k] = p.tlogt[k];
+        for (int k = lane; k < p.nmax; k += kWave) sD[k] = p.dfix[k];
 
     // ---------------- stage 1b: neighbourhood membership (rpf.cpp:556-586) ----------------------
     const int x0 = max(x - b, 0), x1 = min(x + b, W - 1);
@@ -210,7 +295,7 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
         const int myc = lane & 31;
         const bool chain = myc < kNDim;
         const bool is_sq = lane >= 32;
-        for (int j0 = 0; j0 < n; j0 += kStageChunk) {
+        for (int j0 = 0; j0 < ((p.stage_mask & 1) ? n : 0); j0 += kStageChunk) {
             const int cnt = min(kStageChunk, n - j0);
             for (int e = lane; e < kNDim * kStageChunk; e += kWave) {
                 const int c = e / kStageChunk, t = e % kStageChunk;
@@ -219,10 +304,20 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             wsync();
             if (chain) {
                 const double *src = sStage + myc * (kStageChunk + 1);
-                if (!is_sq) {
-                    for (int t = 0; t < cnt; ++t) acc = acc + src[t];                     // ops.h:121
+                if (cnt == kStageChunk) { // full chunk: all LDS reads issue up front, only the adds are serial
+                    double v[kStageChunk];
+#pragma unroll
+                    for (int t = 0; t < kStageChunk; ++t) v[t] = src[t];
+                    if (is_sq) {
+#pragma unroll
+                        for (int t = 0; t < kStageChunk; ++t) v[t] = v[t] * v[t];  // ops.h:138 multiplyArrays
+                    }
+#pragma unroll
+                    for (int t = 0; t < kStageChunk; ++t) acc = acc + v[t];         // ops.h:121 / 138 sumArrays
+                } else if (!is_sq) {
+                    for (int t = 0; t < cnt; ++t) acc = acc + src[t];
                 } else {
-                    for (int t = 0; t < cnt; ++t) { const double v = src[t]; acc = acc + v * v; } // ops.h:138
+                    for (int t = 0; t < cnt; ++t) { const double v = src[t]; acc = acc + v * v; }
                 }
             }
             wsync();
@@ -242,9 +337,11 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
     }
 
     // ---------------- stage 3a: normalise, min/max, bin ids (sd.h:229-232, mi.cpp:14-16) --------
+    // bin ids are bytes; a lane's K samples (j = lane + 64*kk) sit in KW consecutive 32-bit words
+    // [column][lane][KW] so that the histogram stage fetches them with one wide LDS read per column.
     const int B = max(1, (int)sqrt((double)n)); // mi.cpp:54
     const double dB = (double)B;
-    for (int c = 0; c < kNDim; ++c) {
+    for (int c = 0; c < ((p.stage_mask & 2) ? kNDim : 0); ++c) {
         const double Mc = sStat[c], SDc = sStat[kNDim + c];
         double zr[K];
         double lo = INFINITY, hi = -INFINITY;
@@ -265,6 +362,9 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
         lo = wave_min(lo);
         hi = wave_max(hi);
         const double range = hi - lo;
+        uint32_t w[KW];
+#pragma unroll
+        for (int q4 = 0; q4 < KW; ++q4) w[q4] = 0u;
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) {
             const int j = lane + kWave * kk;
@@ -276,60 +376,115 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
                     bin = min(bin, B - 1);
                     bin = max(bin, 0);
                 }
-                sBins[c * p.nmax_pad + j] = (uint8_t)bin;
+                w[kk >> 2] |= (uint32_t)bin << (8 * (kk & 3));
             }
         }
+        store_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, w);
     }
     wsync();
     if (p.dbg.bin_hash != nullptr && lane < kNDim) {
         uint32_t h = 2166136261u;
-        for (int j = 0; j < n; ++j) h = fnv1a_u16(h, sBins[lane * p.nmax_pad + j]);
+        const uint8_t *bytes = reinterpret_cast<const uint8_t *>(sBinW + (size_t)lane * kWave * KW);
+        for (int j = 0; j < n; ++j) h = fnv1a_u16(h, bytes[(j & 63) * (KW * 4) + (j >> 6)]);
         p.dbg.bin_hash[pix * kNDim + lane] = h;
     }
 
     // ---------------- stage 3b: histograms -> mutual information (mi.cpp:45-90) -----------------
-    for (int t = lane; t < B * B; t += kWave) sHist[t] = 0u; // the staging buffer of stage 2 aliased this region
-    wsync();
-    const double TN = Tl((uint32_t)n);
-    const double dn = (double)n;
-    for (int c = 0; c < kNDim; ++c) { // marginal term sum_i T[hx_i] of every column
-        for (int j = lane; j < n; j += kWave) atomicAdd(&sHist[sBins[c * p.nmax_pad + j]], 1u);
-        wsync();
-        double a = 0.0;
-        for (int t = lane; t < B; t += kWave) {
-            const uint32_t h = sHist[t];
-            sHist[t] = 0u;
-            a += Tl(h);
+    // mi.cpp:79-86 over integer counts:  N*MI = T[N] + sum_ij T[J_ij] - sum_i T[hx_i] - sum_j T[hy_j],
+    // T[k] = k ln k.  T is tabulated in 2^-44 fixed point, so every sum below is an exact integer sum:
+    // the result does not depend on the order in which lanes hit a cell, a single-bin column gives exactly
+    // MI == 0 like the reference (pX == 1 => every log term is log(1)), and no log is evaluated here.
+    // Each increment is a returning LDS atomic; the old count c contributes D[c] = T[c+1]-T[c], which
+    // telescopes to T[J] per cell.  The histogram is cleared by wide stores issued right behind the
+    // atomics (one wave's LDS operations execute in order), so consecutive pairs need no barrier.
+    zero_words(sHist, B * B, lane);
+    uint32_t vmask = 0u; // which of this lane's K samples exist
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) vmask |= (lane + kWave * kk < n) ? (1u << kk) : 0u;
+    if (p.stage_mask & 4) {
+        // marginals: sum_i T[hx_i] per column, columns in two groups of <= 16 accumulators
+#pragma unroll 1
+        for (int g = 0; g < 2; ++g) {
+            uint64_t acc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc[i] = 0ull;
+                const int c = g * 16 + i;
+                if (c < kNDim) {
+                    uint32_t w[KW];
+                    load_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, w);
+                    uint64_t a = 0ull;
+#pragma unroll
+                    for (int kk = 0; kk < K; ++kk)
+                        if (vmask & (1u << kk)) {
+                            const uint32_t old = atomicAdd(&sHist[(w[kk >> 2] >> (8 * (kk & 3))) & 0xffu], 1u);
+                            a += Dl(old);
+                        }
+                    zero_words(sHist, B, lane);
+                    acc[i] = a;
+                }
+            }
+            const uint64_t tot = reduce16(acc, lane);
+            const int slot = g * 16 + reduce16_slot(lane);
+            if ((lane & 3) == 0 && slot < kNDim) sHXf[slot] = tot;
         }
-        a = wave_sum(a);
-        if (lane == 0) sHX[c] = a;
-        wsync();
+        // joint histograms, grouped by an anchor column whose (bin * B) stays in registers
+        //   anchors 0..3 = r0, r1, p0, p1 with partners f0..f11, c0..c2 ; anchors 4..6 = c0..c2 with f0..f11
+#pragma unroll 1
+        for (int g = 0; g < 7; ++g) {
+            const int acol = g < 2 ? kColR + g : (g < 4 ? kColP + (g - 2) : kColC + (g - 4));
+            const int np = g < 4 ? 15 : 12;
+            uint32_t akey[K];
+            {
+                uint32_t w[KW];
+                load_words<KW>(sBinW + ((size_t)acol * kWave + lane) * KW, w);
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) akey[kk] = ((w[kk >> 2] >> (8 * (kk & 3))) & 0xffu) * (uint32_t)B;
+            }
+            uint64_t acc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc[i] = 0ull;
+                if (i < np) { // wave-uniform
+                    const int bcol = i < 12 ? kColF + i : kColC + (i - 12);
+                    uint32_t w[KW];
+                    load_words<KW>(sBinW + ((size_t)bcol * kWave + lane) * KW, w);
+                    uint64_t a = 0ull;
+#pragma unroll
+                    for (int kk = 0; kk < K; ++kk)
+                        if (vmask & (1u << kk)) {
+                            const uint32_t key = akey[kk] + ((w[kk >> 2] >> (8 * (kk & 3))) & 0xffu); // mi.cpp:39
+                            const uint32_t old = atomicAdd(&sHist[key], 1u);
+                            a += Dl(old);
+                        }
+                    zero_words(sHist, B * B, lane);
+                    acc[i] = a;
+                }
+            }
+            const uint64_t tot = reduce16(acc, lane);
+            const int i = reduce16_slot(lane);
+            if ((lane & 3) == 0 && i < np) {
+                // pair index in ComputeCFWeights call order (rpf.cpp:416-442)
+                int pr;
+                if (g < 4) pr = i < 12 ? i * 4 + (g < 2 ? g : 2 + (g - 2)) : 48 + (i - 12) * 16 + (g < 2 ? g : 2 + (g - 2));
+                else pr = 48 + (g - 4) * 16 + 4 + i;
+                sPairF[pr] = tot;
+            }
+        }
     }
-    for (int pr = 0; pr < kNPair; ++pr) {
-        const int ca = c_pairs.a[pr], cb = c_pairs.b[pr];
-        const uint8_t *ba = sBins + ca * p.nmax_pad;
-        const uint8_t *bb = sBins + cb * p.nmax_pad;
-        for (int j = lane; j < n; j += kWave) atomicAdd(&sHist[(uint32_t)ba[j] * B + bb[j]], 1u); // mi.cpp:39
-        wsync();
-        double a = 0.0;
-        for (int t = lane; t < B * B; t += kWave) {
-            const uint32_t h = sHist[t];
-            sHist[t] = 0u;
-            a += Tl(h);
-        }
-        a = wave_sum(a);
-        // sum_ij pXY ln(pXY/(pX pY)) = (N ln N + sum J ln J - sum hx ln hx - sum hy ln hy) / N
-        // A column whose samples all fall in one bin (constant feature, or B == 1) has pX == 1, so every
-        // term of mi.cpp:84 is pXY*log(1): the reference returns exactly 0, and that exact zero decides
-        // whether rpf.cpp:465/470 divide 0 by 0.  sum_i T[hx_i] == T[N] iff the column has a single bin.
-        const double hxa = sHX[ca], hxb = sHX[cb];
-        const double mi = (hxa == TN || hxb == TN) ? 0.0 : (TN + a - hxa - hxb) / dn;
-        if (lane == 0) {
+    wsync();
+    {
+        const int64_t TNf = (int64_t)p.tfix[n];
+        const double dn = (double)n;
+        for (int pr = lane; pr < kNPair; pr += kWave) {
+            const int ca = c_pairs.a[pr], cb = c_pairs.b[pr];
+            const int64_t f = TNf + (int64_t)sPairF[pr] - (int64_t)sHXf[ca] - (int64_t)sHXf[cb];
+            const double mi = ldexp((double)f, -kTFixBits) / dn;
             sMI[pr] = mi;
             if (p.dbg.mi) p.dbg.mi[pix * kNPair + pr] = mi;
         }
-        wsync();
     }
+    wsync();
 
     // ---------------- stage 3c: alpha, beta, W_r_c (rpf.cpp:444-487), every lane redundantly ----
     double alpha[3], beta[kNFeat], wrc;
@@ -410,7 +565,7 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
         }
     }
     bool bad = false;
-    for (int i0 = 0; i0 < S; i0 += 8) {
+    for (int i0 = 0; i0 < ((p.stage_mask & 8) ? S : 0); i0 += 8) {
         double sw[8], s0[8], s1[8], s2[8];
 #pragma unroll
         for (int ii = 0; ii < 8; ++ii) { sw[ii] = 0.0; s0[ii] = 0.0; s1[ii] = 0.0; s2[ii] = 0.0; }
@@ -535,19 +690,32 @@ hipError_t launch_filter_k(const PassParams &p, const LdsLayout &L, bool t_in_ld
 
 static uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 
-LdsLayout lds_layout(int S, int nmax, int nmax_pad, int bmax, bool t_in_lds) {
+int samples_per_lane(int nmax) {
+    const int per_lane = (nmax + kWave - 1) / kWave;
+    const int ks[] = {1, 2, 4, 7, 13, 25, 49};
+    for (int k : ks)
+        if (per_lane <= k) return k;
+    return 0;
+}
+
+bool table_in_lds(int nmax) { return (uint32_t)nmax * 8u <= 8192u; }
+
+LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     LdsLayout L{};
+    const int K = samples_per_lane(nmax);
+    const uint32_t KW = (uint32_t)(K + 3) / 4;
     uint32_t o = 0;
     L.off_T = o;
-    if (t_in_lds) o += align_up((uint32_t)(nmax + 1) * 8u, 16);
+    if (t_in_lds) o += align_up((uint32_t)nmax * 8u, 16);
     L.off_stat = o; o += align_up(2 * kNDim * 8, 16);
     L.off_hx = o; o += align_up(kNDim * 8, 16);
+    L.off_pair = o; o += align_up(kNPair * 8, 16);
     L.off_mi = o; o += align_up(kNPair * 8, 16);
     L.off_own = o; o += align_up((uint32_t)S * kNDim * 8u, 16);
     L.off_off = o; o += align_up((uint32_t)nmax * 4u, 16);
     L.off_union = o;
     const uint32_t stage = align_up(kNDim * (kStageChunk + 1) * 8, 16);
-    const uint32_t bins = align_up((uint32_t)kNDim * (uint32_t)nmax_pad, 16);
+    const uint32_t bins = align_up((uint32_t)kNDim * kWave * KW * 4u, 16);
     L.off_hist = o + bins;
     const uint32_t hist = align_up((uint32_t)bmax * (uint32_t)bmax * 4u, 16);
     const uint32_t uni = (bins + hist) > stage ? (bins + hist) : stage;
@@ -565,23 +733,24 @@ hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s) {
 }
 
 hipError_t launch_filter_pass(const PassParams &p, hipStream_t s, uint32_t *lds_bytes_out) {
-    const bool t_in_lds = (uint32_t)(p.nmax + 1) * 8u <= 8192u;
-    const LdsLayout L = lds_layout(p.S, p.nmax, p.nmax_pad, p.bmax, t_in_lds);
+    const bool t_in_lds = table_in_lds(p.nmax);
+    const LdsLayout L = lds_layout(p.S, p.nmax, p.bmax, t_in_lds);
     if (lds_bytes_out) *lds_bytes_out = L.total;
     if ((int)L.total > max_lds_per_block()) return hipErrorInvalidValue;
     const int64_t P = (int64_t)(p.row_end - p.row_begin) * p.W;
     if (P <= 0) return hipSuccess;
     const int64_t band = (P + 7) / 8;
     const unsigned grid = (unsigned)(band * 8);
-    const int per_lane = (p.nmax + kWave - 1) / kWave;
-    if (per_lane <= 1) return launch_filter_k<1>(p, L, t_in_lds, grid, s);
-    if (per_lane <= 2) return launch_filter_k<2>(p, L, t_in_lds, grid, s);
-    if (per_lane <= 4) return launch_filter_k<4>(p, L, t_in_lds, grid, s);
-    if (per_lane <= 7) return launch_filter_k<7>(p, L, t_in_lds, grid, s);
-    if (per_lane <= 13) return launch_filter_k<13>(p, L, t_in_lds, grid, s);
-    if (per_lane <= 25) return launch_filter_k<25>(p, L, t_in_lds, grid, s);
-    if (per_lane <= 49) return launch_filter_k<49>(p, L, t_in_lds, grid, s);
-    return hipErrorInvalidValue;
+    switch (samples_per_lane(p.nmax)) {
+    case 1: return launch_filter_k<1>(p, L, t_in_lds, grid, s);
+    case 2: return launch_filter_k<2>(p, L, t_in_lds, grid, s);
+    case 4: return launch_filter_k<4>(p, L, t_in_lds, grid, s);
+    case 7: return launch_filter_k<7>(p, L, t_in_lds, grid, s);
+    case 13: return launch_filter_k<13>(p, L, t_in_lds, grid, s);
+    case 25: return launch_filter_k<25>(p, L, t_in_lds, grid, s);
+    case 49: return launch_filter_k<49>(p, L, t_in_lds, grid, s);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_colour_from_planes(const float *planes, double *colour, uint64_t ps, hipStream_t s) {

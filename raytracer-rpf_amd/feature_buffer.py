@@ -126,7 +126,7 @@ def synth_planes(W, H, S, seed=20250103, sigma_f=0.05, sigma_c=1e-4, row0=0, xp=
     # first-hit features: smooth in pFilm + Gaussian jitter
     nx = 0.35 * xp.sin(3.0 * X) + sigma_f * G(10)
     ny = 0.35 * xp.cos(2.0 * Y) + sigma_f * G(11)
-    nz = xp.sqrt(1.0 - 0.35 * 0.35 * 2.0 * 0.5) + 0.05 * xp.sin(X + Y) + sigma_f * G(12)
+    nz = math.sqrt(1.0 - 0.35 * 0.35 * 2.0 * 0.5) + 0.05 * xp.sin(X + Y) + sigma_f * G(12)
     step = xp.cast((xp.cast(xp.floor(fx / 256.0), xp.i64) % 2), xp.f64)
     p0x = 0.01 * fx + sigma_f * G(13)
     p0y = 0.01 * fy + sigma_f * G(14)

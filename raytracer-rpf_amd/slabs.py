@@ -1,0 +1,56 @@
+"""Row-slab partitioning of the image across ranks and the neighbour halo exchange.
+
+The filter window of a pixel reaches b = (box-1)/2 rows up and down (rpf.cpp:561-571) and nothing else is
+shared between pixels, so the image shards into contiguous row slabs, one per GPU / process, and the only
+data-path communication is a send/recv of b boundary rows with the rank above and the rank below
+(`torch.distributed` P2P: RCCL over xGMI on the GPUs, gloo in the CPU tests).  Feature planes never change
+between passes, so their halo is exchanged once; colours change every pass and are re-exchanged before
+each pass.  Planes are laid out [plane][row][x][s], so a halo is one contiguous span per plane.
+"""
+from collections import namedtuple
+
+Slab = namedtuple("Slab", "row0 row1 halo_top halo_bottom")  # owned image rows [row0,row1); halo rows held
+
+
+def partition_rows(H, world, rank):
+    """contiguous, near-equal split of H rows: rank r owns [r*H//world, (r+1)*H//world)"""
+    return (rank * H) // world, ((rank + 1) * H) // world
+
+
+def slab_for(H, world, rank, halo):
+    a, b = partition_rows(H, world, rank)
+    return Slab(a, b, min(halo, a), min(halo, H - b))
+
+
+def buffer_rows(slab):
+    """rows present in the rank's buffers, and the [row_begin,row_end) range the rank filters"""
+    n = slab.row1 - slab.row0
+    return slab.halo_top + n + slab.halo_bottom, slab.halo_top, slab.halo_top + n
+
+
+def exchange_halo(t, slab, rank, world, group=None):
+    """Refresh the halo rows of ``t`` ([planes, H_buf, W, S], any dtype) from the neighbouring ranks' owned
+    boundary rows.  Collective over (rank-1, rank, rank+1); a no-op for world == 1."""
+    import torch.distributed as dist
+    if world == 1:
+        return
+    n_own = slab.row1 - slab.row0
+    top0 = slab.halo_top  # first owned buffer row
+    ops, recvs = [], []
+    if rank > 0 and slab.halo_top > 0:
+        h = slab.halo_top
+        send_up = t[:, top0:top0 + h].contiguous()          # my first h owned rows -> bottom halo of rank-1
+        recv_up = t.new_empty((t.shape[0], h) + tuple(t.shape[2:]))
+        ops += [dist.P2POp(dist.isend, send_up, rank - 1, group), dist.P2POp(dist.irecv, recv_up, rank - 1, group)]
+        recvs.append((recv_up, 0, h))
+    if rank < world - 1 and slab.halo_bottom > 0:
+        h = slab.halo_bottom
+        send_dn = t[:, top0 + n_own - h:top0 + n_own].contiguous()  # my last h owned rows -> top halo of rank+1
+        recv_dn = t.new_empty((t.shape[0], h) + tuple(t.shape[2:]))
+        ops += [dist.P2POp(dist.isend, send_dn, rank + 1, group), dist.P2POp(dist.irecv, recv_dn, rank + 1, group)]
+        recvs.append((recv_dn, top0 + n_own, h))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for buf, r0, h in recvs:
+        t[:, r0:r0 + h].copy_(buf)

@@ -94,9 +94,10 @@ def test_ref_abort_status_on_constant_feature(ctx, hipmod, oracle):
     # the same buffer completes under the EPS policy, identically on both sides
     got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS), box=7)
     want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7, policy=oracle.DEGEN_EPS))
-    # D terms that are ~1e-16 rounding residue are divided by (residue + eps=1e-10) under EPS: the ratio
-    # inherits the residue's relative noise / eps ~ 1e-6
-    check_pass(got, want, ab_rtol=1e-4)
+    # D terms that are pure rounding residue (~1e-14: the device tabulates k ln k in 2^-44 fixed point, the
+    # oracle sums log() terms) are divided by (residue + eps=1e-10) under EPS: the ratio inherits
+    # residue / eps ~ 1e-4 of relative noise.  The colours still agree to the rel-L2 bar.
+    check_pass(got, want, ab_rtol=5e-3)
     assert np.isfinite(got["colour"]).all()
 
 
