@@ -153,6 +153,11 @@ int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *desc, int32_t box, c
 /* counters of the most recent rpf_filter / rpf_filter_device / rpf_filter_pass_debug call */
 int32_t rpf_query_counters(rpf_ctx *ctx, rpf_counters *out);
 
+/* device self-test: the kernels divide by wave-uniform divisors with a hoisted reciprocal (3 instructions per
+ * quotient); this compares n pseudo-random quotients bit-for-bit with the compiler's IEEE fp64 division.
+ * mode 0: operand magnitudes of the filter (2^-40..2^40); mode 1: 2^-600..2^600 (exercises the fallback). */
+int32_t rpf_selftest_udiv(rpf_ctx *ctx, uint64_t n, uint64_t seed, int32_t mode, uint64_t *mismatches);
+
 /* LDS bytes per workgroup the fused kernel needs for (S, box); > device limit => RPF_E_UNSUPPORTED */
 int64_t rpf_lds_bytes_required(int32_t S, int32_t box);
 

@@ -445,6 +445,18 @@ int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *d, int32_t box, cons
     return RPF_OK;
 }
 
+int32_t rpf_selftest_udiv(rpf_ctx *ctx, uint64_t n, uint64_t seed, int32_t mode, uint64_t *mismatches) {
+    if (!ctx || !mismatches) return RPF_E_BADARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(ctx->d_nred, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(launch_udiv_selftest(n, seed, mode, ctx->d_nred, ctx->stream));
+    unsigned long long r = 0;
+    HIP_TRY(hipMemcpyAsync(&r, ctx->d_nred, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *mismatches = r;
+    return RPF_OK;
+}
+
 int32_t rpf_query_counters(rpf_ctx *ctx, rpf_counters *out) {
     if (!ctx || !out) return RPF_E_BADARG;
     *out = ctx->counters;

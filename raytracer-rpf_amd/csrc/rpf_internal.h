@@ -12,7 +12,7 @@ constexpr int kNFeat = RPF_NFEAT; // 12
 constexpr int kNPair = RPF_NPAIR; // 96
 constexpr int kColP = 0, kColC = 2, kColR = 5, kColF = 7;
 constexpr int kWave = 64;
-constexpr int kStageChunk = 32; // samples staged per step of the in-order (reference-order) sums
+constexpr int kStageChunk = 64; // samples staged per step of the in-order (reference-order) sums
 
 // everything one pass needs, passed by value to the kernels
 struct PassParams {
@@ -53,5 +53,6 @@ hipError_t launch_reduce(const double *colour, const float *ray_weight, float *s
 hipError_t launch_nbhd_reduce(const int32_t *nbhd, int W, int row_begin, int row_end, unsigned long long *out2,
                               hipStream_t s);
 int max_lds_per_block();
+hipError_t launch_udiv_selftest(uint64_t n, uint64_t seed, int mode, unsigned long long *d_mismatch, hipStream_t s);
 
 } // namespace rpf

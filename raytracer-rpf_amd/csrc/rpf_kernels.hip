@@ -163,6 +163,29 @@ __device__ __forceinline__ uint64_t reduce16(const uint64_t (&a)[16], int lane) 
     return v;
 }
 
+// 4 accumulators per lane -> wave totals; afterwards a lane holds the total of accumulator reduce4_slot(lane)
+__device__ __forceinline__ int reduce4_slot(int lane) { return ((lane >> 5) & 1) * 2 + ((lane >> 4) & 1); }
+__device__ __forceinline__ uint64_t reduce4(const uint64_t (&a)[4], int lane) {
+    uint64_t b2[2];
+    {
+        const bool up = (lane & 32) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint64_t keep = up ? a[i + 2] : a[i], send = up ? a[i] : a[i + 2];
+            b2[i] = keep + (uint64_t)__shfl_xor((unsigned long long)send, 32, 64);
+        }
+    }
+    uint64_t v;
+    {
+        const bool up = (lane & 16) != 0;
+        const uint64_t keep = up ? b2[1] : b2[0], send = up ? b2[0] : b2[1];
+        v = keep + (uint64_t)__shfl_xor((unsigned long long)send, 16, 64);
+    }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, m, 64);
+    return v;
+}
+
 // value of column c of the sample at plane offset `off`: colours come from the fp64 colour planes
 __device__ __forceinline__ double load_col(const PassParams &p, int c, uint32_t off) {
     if (c >= kColC && c < kColC + 3) return p.col_in[(uint64_t)(c - kColC) * p.plane_stride + off];
@@ -195,24 +218,150 @@ __global__ __launch_bounds__(256) void pixel_stats_kernel(PassParams p) {
     }
 }
 
+// ---- exact fp64 division by a wave-uniform divisor ---------------------------------------------------
+// hipcc lowers a/b (f64) to v_div_scale x2, v_rcp_f64, two Newton steps on the reciprocal, q0 = a*r,
+// rem = fma(-b,q0,a), q = fma(rem,r,q0) (v_div_fmas), v_div_fixup.  For operands in the normal range the
+// scale steps are the identity and the fixup passes q through, so the quotient is exactly
+// fma(fma(-b, a*r, a), r, a*r) with r depending on b only.  Every division of stage 3a has a divisor that
+// is the same for all samples of a column, so r is refined ONCE per column and each sample pays three
+// instructions.  The numerators there are differences of fp32-valued samples and their means: 0 or of
+// magnitude within [2^-215, 2^130], so with the divisor inside [2^-100, 2^100] every intermediate stays in
+// the normal range; a column whose divisor is outside that window takes the plain operator instead
+// (wave-uniform branch).  Bit-identity with a/b: tests/test_gpu_parity.py::test_uniform_divisor_division_is_exact.
+struct UDiv {
+    double b, r;
+    bool fast;
+};
+__device__ __forceinline__ UDiv udiv_prepare(double b) {
+    UDiv d;
+    d.b = b;
+    const double ab = fabs(b);
+    d.fast = (ab > 0x1p-100) && (ab < 0x1p100);
+    double r = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    d.r = r;
+    return d;
+}
+// valid when d.fast and the numerator is 0 or has magnitude in [2^-400, 2^400]
+__device__ __forceinline__ double udiv_fast(double a, const UDiv &d) {
+    const double q0 = a * d.r;
+    const double rem = fma(-d.b, q0, a);
+    return fma(rem, d.r, q0);
+}
+__device__ __forceinline__ double udiv(double a, const UDiv &d) {
+    const double aa = fabs(a);
+    const bool ok = d.fast && ((aa == 0.0) || ((aa > 0x1p-400) && (aa < 0x1p400)));
+    return ok ? udiv_fast(a, d) : a / d.b;
+}
+
+// 32 floats per lane -> per-slot minimum over the wave (transposed butterfly, 32 exchanges); afterwards a
+// lane holds the minimum of slot ((lane>>1) & 31)
+__device__ __forceinline__ float reduce32_min(float (&a)[32], int lane) {
+    float b16[16], b8[8], b4[4], b2[2];
+    {
+        const bool up = (lane & 32) != 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float keep = up ? a[i + 16] : a[i], send = up ? a[i] : a[i + 16];
+            b16[i] = fminf(keep, __shfl_xor(send, 32, 64));
+        }
+    }
+    {
+        const bool up = (lane & 16) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float keep = up ? b16[i + 8] : b16[i], send = up ? b16[i] : b16[i + 8];
+            b8[i] = fminf(keep, __shfl_xor(send, 16, 64));
+        }
+    }
+    {
+        const bool up = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float keep = up ? b8[i + 4] : b8[i], send = up ? b8[i] : b8[i + 4];
+            b4[i] = fminf(keep, __shfl_xor(send, 8, 64));
+        }
+    }
+    {
+        const bool up = (lane & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float keep = up ? b4[i + 2] : b4[i], send = up ? b4[i] : b4[i + 2];
+            b2[i] = fminf(keep, __shfl_xor(send, 4, 64));
+        }
+    }
+    float v;
+    {
+        const bool up = (lane & 2) != 0;
+        const float keep = up ? b2[1] : b2[0], send = up ? b2[0] : b2[1];
+        v = fminf(keep, __shfl_xor(send, 2, 64));
+    }
+    v = fminf(v, __shfl_xor(v, 1, 64));
+    return v;
+}
+__device__ __forceinline__ int reduce32_slot(int lane) { return (lane >> 1) & 31; }
+// where slot s of reduce32 ends up: lanes with ((lane>>1)&31) == s, e.g. lane 2*s
+// (bit order: slot bit4 <- lane bit5, bit3 <- lane bit4, ... bit0 <- lane bit1)
+
+// 16 doubles per lane -> per-slot wave sums (same butterfly as reduce16 on doubles)
+__device__ __forceinline__ double reduce16_sum(const double (&a)[16], int lane) {
+    double b8[8], b4[4], b2[2];
+    {
+        const bool up = (lane & 32) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double keep = up ? a[i + 8] : a[i], send = up ? a[i] : a[i + 8];
+            b8[i] = keep + __shfl_xor(send, 32, 64);
+        }
+    }
+    {
+        const bool up = (lane & 16) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double keep = up ? b8[i + 4] : b8[i], send = up ? b8[i] : b8[i + 4];
+            b4[i] = keep + __shfl_xor(send, 16, 64);
+        }
+    }
+    {
+        const bool up = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double keep = up ? b4[i + 2] : b4[i], send = up ? b4[i] : b4[i + 2];
+            b2[i] = keep + __shfl_xor(send, 8, 64);
+        }
+    }
+    double v;
+    {
+        const bool up = (lane & 4) != 0;
+        const double keep = up ? b2[1] : b2[0], send = up ? b2[0] : b2[1];
+        v = keep + __shfl_xor(send, 4, 64);
+    }
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // the fused per-pixel kernel
-//   K         compile-time bound on samples per lane: K*64 >= nmax
-//   T_IN_LDS  keep the k ln k table in LDS (small neighbourhoods) instead of reading it through L1
+//   K         compile-time bound on samples per lane: K*64 >= nmax ; lane owns samples j = lane + 64*kk
+//   T_IN_LDS  keep the D table in LDS (small neighbourhoods) instead of reading it through L1
 // ------------------------------------------------------------------------------------------------
 template <int K, bool T_IN_LDS>
 __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayout L) {
+    constexpr int KW = (K + 3) / 4;          // 32-bit words of bin ids per lane and column
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int KW = (K + 3) / 4; // 32-bit words of bin ids per lane and column
     uint64_t *sD = reinterpret_cast<uint64_t *>(smem + L.off_T); // D[c] = T[c+1]-T[c], 2^-44 fixed point
-    double *sStat = reinterpret_cast<double *>(smem + L.off_stat); // M[19], SD[19]
+    double *sStat = reinterpret_cast<double *>(smem + L.off_stat); // M[19], SD[19], xmin[19], xmax[19]
     uint64_t *sHXf = reinterpret_cast<uint64_t *>(smem + L.off_hx);     // sum_i T[hx_i] per column (fixed point)
     uint64_t *sPairF = reinterpret_cast<uint64_t *>(smem + L.off_pair); // sum_ij T[J_ij] per pair (fixed point)
     double *sMI = reinterpret_cast<double *>(smem + L.off_mi);     // 96 MI values
     double *sOwn = reinterpret_cast<double *>(smem + L.off_own);   // raw own samples [S][19]
     uint32_t *sOff = reinterpret_cast<uint32_t *>(smem + L.off_off);
-    double *sStage = reinterpret_cast<double *>(smem + L.off_union); // [19][kStageChunk+1] (aliases bins)
-    uint32_t *sBinW = reinterpret_cast<uint32_t *>(smem + L.off_union); // bin ids [19][64][KW] words
+    double *sStage = reinterpret_cast<double *>(smem + L.off_union);    // [19][kStageChunk+1] (aliases bins)
+    uint32_t *sBinW = reinterpret_cast<uint32_t *>(smem + L.off_union); // bin ids [19][64][KW] words (K > 8)
     uint32_t *sHist = reinterpret_cast<uint32_t *>(smem + L.off_hist);
 
     const int lane = threadIdx.x;
@@ -244,34 +393,39 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
 
     for (int s = lane; s < S; s += kWave) sOff[s] = (uint32_t)(pix * S + s); // own samples first
 
-    double m12[kNFeat], lim12[kNFeat];
-#pragma unroll
-    for (int k = 0; k < kNFeat; ++k) {
-        m12[k] = p.pmean[(uint64_t)k * HW + pix];
-        lim12[k] = p.pstd[(uint64_t)k * HW + pix] * 3.0; // multiplyArray(std, 3), rpf.cpp:579
-    }
     int n = S;
-    for (int q0 = 0; q0 < ncand; q0 += kWave) {
-        const int qq = q0 + lane;
-        bool pass = false;
-        uint32_t off = 0;
-        if (qq < ncand) {
-            int cell = qq / S;
-            const int s = qq - cell * S;
-            if (cell >= centre_rank) ++cell;          // rpf.cpp:565: skip the centre pixel
-            const int ix = cell / nyv;                 // xn outer ascending (rpf.cpp:562)
-            const int iy = cell - ix * nyv;            // yn inner ascending (rpf.cpp:563)
-            off = (uint32_t)(((uint64_t)(y0 + iy) * W + (x0 + ix)) * S + s);
-            pass = true;
+    {
+        double m12[kNFeat], lim12[kNFeat];
 #pragma unroll
-            for (int k = 0; k < kNFeat; ++k) {
-                const double a = fabs((double)p.planes[(uint64_t)(kColF + k) * p.plane_stride + off] - m12[k]);
-                if (a >= lim12[k]) pass = false;       // allLessThan: fails iff a >= b (ops.h:101-104)
-            }
+        for (int k = 0; k < kNFeat; ++k) {
+            m12[k] = p.pmean[(uint64_t)k * HW + pix];
+            lim12[k] = p.pstd[(uint64_t)k * HW + pix] * 3.0; // multiplyArray(std, 3), rpf.cpp:579
         }
-        const unsigned long long mask = __ballot(pass);
-        if (pass) sOff[n + __popcll(mask & ((1ull << lane) - 1ull))] = off;
-        n += __popcll(mask);
+        for (int q0 = 0; q0 < ncand; q0 += kWave) {
+            const int qq = q0 + lane;
+            bool pass = false;
+            uint32_t off = 0;
+            if (qq < ncand) {
+                int cell = qq / S;
+                const int s = qq - cell * S;
+                if (cell >= centre_rank) ++cell;          // rpf.cpp:565: skip the centre pixel
+                const int ix = cell / nyv;                 // xn outer ascending (rpf.cpp:562)
+                const int iy = cell - ix * nyv;            // yn inner ascending (rpf.cpp:563)
+                off = (uint32_t)(((uint64_t)(y0 + iy) * W + (x0 + ix)) * S + s);
+                float f[kNFeat];
+#pragma unroll
+                for (int k = 0; k < kNFeat; ++k) f[k] = p.planes[(uint64_t)(kColF + k) * p.plane_stride + off];
+                pass = true;
+#pragma unroll
+                for (int k = 0; k < kNFeat; ++k) {
+                    const double a = fabs((double)f[k] - m12[k]);
+                    if (a >= lim12[k]) pass = false;       // allLessThan: fails iff a >= b (ops.h:101-104)
+                }
+            }
+            const unsigned long long mask = __ballot(pass);
+            if (pass) sOff[n + __popcll(mask & ((1ull << lane) - 1ull))] = off;
+            n += __popcll(mask);
+        }
     }
     wsync();
     if (lane == 0) p.nbhd[pix] = n;
@@ -289,31 +443,74 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
     }
 
     // ---------------- stage 2: mean / std over the neighbourhood, reference order ---------------
-    // lanes 0..18 carry sum(x) of column `lane`, lanes 32..50 carry sum(x*x) of column `lane-32`.
+    // Chunks of 64 samples: lane t gathers all 19 values of sample j0+t (the next chunk is already in
+    // flight in registers), stages them as doubles [column][t] in LDS, then lanes 0..18 run the in-order
+    // sum(x) chain of column `lane` and lanes 32..50 the sum(x*x) chain of column `lane-32`.
+    // The per-column min / max of x ride along (order independent): z = (x-M)/SD is monotone in x, so
+    // min z = z(min x) and max z = z(max x) exactly, which is all mi.cpp:47-50 needs.
+    float fmn[16], fmx[16];  // non-colour columns: 0,1 then 5..18
+    double cmn[3], cmx[3];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { fmn[i] = INFINITY; fmx[i] = -INFINITY; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { cmn[i] = INFINITY; cmx[i] = -INFINITY; }
     {
         double acc = 0.0;
         const int myc = lane & 31;
         const bool chain = myc < kNDim;
         const bool is_sq = lane >= 32;
-        for (int j0 = 0; j0 < ((p.stage_mask & 1) ? n : 0); j0 += kStageChunk) {
-            const int cnt = min(kStageChunk, n - j0);
-            for (int e = lane; e < kNDim * kStageChunk; e += kWave) {
-                const int c = e / kStageChunk, t = e % kStageChunk;
-                if (t < cnt) sStage[c * (kStageChunk + 1) + t] = load_col(p, c, sOff[j0 + t]);
+        const int nrun = (p.stage_mask & 1) ? n : 0;
+        float vf[16];
+        double vd[3];
+        auto fetch = [&](int j) {
+            if (j < nrun) {
+                const uint32_t off = sOff[j];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) vf[i] = p.planes[(uint64_t)(i < 2 ? i : i + 3) * p.plane_stride + off];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) vd[i] = p.col_in[(uint64_t)i * p.plane_stride + off];
+            }
+        };
+        fetch(lane);
+        for (int j0 = 0; j0 < nrun; j0 += kStageChunk) {
+            const int cnt = min(kStageChunk, nrun - j0);
+            if (lane < cnt) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    sStage[(i < 2 ? i : i + 3) * (kStageChunk + 1) + lane] = (double)vf[i];
+                    fmn[i] = fminf(fmn[i], vf[i]);
+                    fmx[i] = fmaxf(fmx[i], vf[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    sStage[(kColC + i) * (kStageChunk + 1) + lane] = vd[i];
+                    cmn[i] = fmin(cmn[i], vd[i]);
+                    cmx[i] = fmax(cmx[i], vd[i]);
+                }
+                if (j0 + lane < S) { // own samples are entries 0..S-1 of the neighbourhood
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sOwn[(j0 + lane) * kNDim + (i < 2 ? i : i + 3)] = (double)vf[i];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) sOwn[(j0 + lane) * kNDim + kColC + i] = vd[i];
+                }
             }
             wsync();
+            fetch(j0 + kStageChunk + lane); // next chunk's gathers overlap the serial chains below
             if (chain) {
                 const double *src = sStage + myc * (kStageChunk + 1);
-                if (cnt == kStageChunk) { // full chunk: all LDS reads issue up front, only the adds are serial
-                    double v[kStageChunk];
+                if (cnt == kStageChunk) { // full chunk: LDS reads issue 16 at a time, only the adds are serial
 #pragma unroll
-                    for (int t = 0; t < kStageChunk; ++t) v[t] = src[t];
-                    if (is_sq) {
+                    for (int h = 0; h < kStageChunk; h += 16) {
+                        double v[16];
 #pragma unroll
-                        for (int t = 0; t < kStageChunk; ++t) v[t] = v[t] * v[t];  // ops.h:138 multiplyArrays
+                        for (int t = 0; t < 16; ++t) v[t] = src[h + t];
+                        if (is_sq) {
+#pragma unroll
+                            for (int t = 0; t < 16; ++t) v[t] = v[t] * v[t];        // ops.h:138 multiplyArrays
+                        }
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) acc = acc + v[t];              // ops.h:121 / 138 sumArrays
                     }
-#pragma unroll
-                    for (int t = 0; t < kStageChunk; ++t) acc = acc + v[t];         // ops.h:121 / 138 sumArrays
                 } else if (!is_sq) {
                     for (int t = 0; t < cnt; ++t) acc = acc + src[t];
                 } else {
@@ -333,62 +530,88 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             if (p.dbg.mean) p.dbg.mean[pix * kNDim + lane] = mean;
             if (p.dbg.stddev) p.dbg.stddev[pix * kNDim + lane] = sd;
         }
+        // wave min / max of x per column -> sStat[38 + c], sStat[57 + c]
+        {
+            float a32[32];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { a32[i] = fmn[i]; a32[16 + i] = -fmx[i]; }
+            const float r = reduce32_min(a32, lane);
+            const int slot = reduce32_slot(lane);
+            if ((lane & 1) == 0) {
+                const int i = slot & 15;
+                const int col = i < 2 ? i : i + 3;
+                if (slot < 16) sStat[2 * kNDim + col] = (double)r;
+                else sStat[3 * kNDim + col] = (double)(-r);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double lo = wave_min(cmn[i]), hi = wave_max(cmx[i]);
+                if (lane == 0) { sStat[2 * kNDim + kColC + i] = lo; sStat[3 * kNDim + kColC + i] = hi; }
+            }
+        }
         wsync();
     }
 
-    // ---------------- stage 3a: normalise, min/max, bin ids (sd.h:229-232, mi.cpp:14-16) --------
-    // bin ids are bytes; a lane's K samples (j = lane + 64*kk) sit in KW consecutive 32-bit words
-    // [column][lane][KW] so that the histogram stage fetches them with one wide LDS read per column.
+    // ---------------- stage 3a: normalise, bin ids (sd.h:229-232, mi.cpp:14-16) ------------------
+    // bin ids are bytes packed per lane: sample kk of the lane is byte kk of KW words per column, written
+    // to LDS [column][lane][KW] over the (now dead) staging buffer of stage 2.
     const int B = max(1, (int)sqrt((double)n)); // mi.cpp:54
     const double dB = (double)B;
-    for (int c = 0; c < ((p.stage_mask & 2) ? kNDim : 0); ++c) {
-        const double Mc = sStat[c], SDc = sStat[kNDim + c];
-        double zr[K];
-        double lo = INFINITY, hi = -INFINITY;
+    {
+        uint32_t offk[K];
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) {
-            const int j = lane + kWave * kk;
-            zr[kk] = 0.0;
-            if (j < n) {
-                const double xv = load_col(p, c, sOff[j]);
-                const double a = xv - Mc;                    // subtractArrays
-                const double z = (SDc == 0.0) ? 0.0 : a / SDc; // divideArrays, ops.h:48
-                zr[kk] = z;
-                lo = fmin(lo, z);
-                hi = fmax(hi, z);
-                if (j < S) sOwn[j * kNDim + c] = xv;
+        for (int kk = 0; kk < K; ++kk) offk[kk] = (lane + kWave * kk < n) ? sOff[lane + kWave * kk] : 0u;
+#pragma unroll 1
+        for (int c = 0; c < ((p.stage_mask & 2) ? kNDim : 0); ++c) {
+            const double Mc = sStat[c], SDc = sStat[kNDim + c];
+            const double xlo = sStat[2 * kNDim + c], xhi = sStat[3 * kNDim + c];
+            const bool sd0 = (SDc == 0.0);
+            const UDiv dsd = udiv_prepare(SDc);
+            const double lo = sd0 ? 0.0 : udiv(xlo - Mc, dsd); // min_element over z (mi.cpp:47,49)
+            const double hi = sd0 ? 0.0 : udiv(xhi - Mc, dsd); // max_element over z (mi.cpp:48,50)
+            const double range = hi - lo;
+            const bool flat = !(hi != lo);                       // mi.cpp:7 / 28 / 34
+            const UDiv drg = udiv_prepare(range);
+            const bool fast = dsd.fast && (flat || drg.fast);   // wave-uniform
+            const bool is_colour = (c >= kColC && c < kColC + 3);
+            const float *fplane = p.planes + (uint64_t)c * p.plane_stride;
+            const double *dplane = p.col_in + (uint64_t)(is_colour ? c - kColC : 0) * p.plane_stride;
+            uint32_t w[KW];
+#pragma unroll
+            for (int q4 = 0; q4 < KW; ++q4) w[q4] = 0u;
+            double xv[K];
+            if (is_colour) {
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) xv[kk] = (kk < (n + kWave - 1) / kWave) ? dplane[offk[kk]] : 0.0;
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) xv[kk] = (kk < (n + kWave - 1) / kWave) ? (double)fplane[offk[kk]] : 0.0;
             }
-        }
-        lo = wave_min(lo);
-        hi = wave_max(hi);
-        const double range = hi - lo;
-        uint32_t w[KW];
 #pragma unroll
-        for (int q4 = 0; q4 < KW; ++q4) w[q4] = 0u;
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk) {
-            const int j = lane + kWave * kk;
-            if (j < n) {
-                int bin = 0;
-                if (hi != lo) {                              // mi.cpp:7 / 28 / 34
-                    const double t = (zr[kk] - lo) / range * dB; // mi.cpp:14
-                    bin = (int)t;
-                    bin = min(bin, B - 1);
-                    bin = max(bin, 0);
+            for (int kk = 0; kk < K; ++kk) {
+                if (lane + kWave * kk < n) {
+                    const double a = xv[kk] - Mc;                                              // subtractArrays
+                    const double z = sd0 ? 0.0 : (fast ? udiv_fast(a, dsd) : a / SDc);         // divideArrays, ops.h:48
+                    int bin = 0;
+                    if (!flat) {
+                        const double t = (fast ? udiv_fast(z - lo, drg) : (z - lo) / range) * dB; // mi.cpp:14
+                        bin = (int)t;
+                        bin = min(bin, B - 1);
+                        bin = max(bin, 0);
+                    }
+                    w[kk >> 2] |= (uint32_t)bin << (8 * (kk & 3));
                 }
-                w[kk >> 2] |= (uint32_t)bin << (8 * (kk & 3));
             }
+            store_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, w);
         }
-        store_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, w);
     }
     wsync();
-    if (p.dbg.bin_hash != nullptr && lane < kNDim) {
+    if (p.dbg.bin_hash != nullptr && lane < kNDim) { // debug only: hash in sample order j = lane + 64*kk
         uint32_t h = 2166136261u;
         const uint8_t *bytes = reinterpret_cast<const uint8_t *>(sBinW + (size_t)lane * kWave * KW);
         for (int j = 0; j < n; ++j) h = fnv1a_u16(h, bytes[(j & 63) * (KW * 4) + (j >> 6)]);
         p.dbg.bin_hash[pix * kNDim + lane] = h;
     }
-
     // ---------------- stage 3b: histograms -> mutual information (mi.cpp:45-90) -----------------
     // mi.cpp:79-86 over integer counts:  N*MI = T[N] + sum_ij T[J_ij] - sum_i T[hx_i] - sum_j T[hy_j],
     // T[k] = k ln k.  T is tabulated in 2^-44 fixed point, so every sum below is an exact integer sum:
@@ -396,82 +619,105 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
     // MI == 0 like the reference (pX == 1 => every log term is log(1)), and no log is evaluated here.
     // Each increment is a returning LDS atomic; the old count c contributes D[c] = T[c+1]-T[c], which
     // telescopes to T[J] per cell.  The histogram is cleared by wide stores issued right behind the
-    // atomics (one wave's LDS operations execute in order), so consecutive pairs need no barrier.
-    zero_words(sHist, B * B, lane);
-    uint32_t vmask = 0u; // which of this lane's K samples exist
+    // atomics (one wave's LDS operations execute in order); the D look-ups of a histogram are issued after
+    // the atomics of the NEXT one, so the LDS pipe always has independent work queued.
+    const int ncell2 = B * B;
+    zero_words(sHist, ncell2, lane);
+    const int kdyn = (n + kWave - 1) / kWave;         // wave-uniform: sample slots kk < kdyn exist
+    uint32_t inc[K];                                  // 1 for an existing sample, 0 for a hole in the last slot
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) vmask |= (lane + kWave * kk < n) ? (1u << kk) : 0u;
+    for (int kk = 0; kk < K; ++kk) inc[kk] = (lane + kWave * kk < n) ? 1u : 0u;
+    const uint32_t hole1 = (uint32_t)min(lane, B - 1);      // harmless targets of the +0 atomics of holes
+    const uint32_t hole2 = (uint32_t)min(lane, ncell2 - 1);
+
+    auto col_words = [&](int c, uint32_t (&w)[KW]) { load_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, w); };
+    // issue the K returning atomics of one histogram, then the clearing stores behind them
+    auto issue = [&](const uint32_t (&key)[K], uint32_t (&old)[K], int cells) {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk)
+            if (kk < kdyn) old[kk] = atomicAdd(&sHist[key[kk]], inc[kk]);
+        zero_words(sHist, cells, lane);
+    };
+    auto consume = [&](const uint32_t (&old)[K]) -> uint64_t {
+        uint64_t d[K];
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) d[kk] = (kk < kdyn) ? Dl(old[kk]) : 0ull;
+        uint64_t a = 0ull;
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) a += inc[kk] ? d[kk] : 0ull;
+        return a;
+    };
+
+#ifndef RPF_X_SKIPMI
     if (p.stage_mask & 4) {
-        // marginals: sum_i T[hx_i] per column, columns in two groups of <= 16 accumulators
+        // Histograms are processed four at a time (runtime loop over groups, so the code stays small): within a
+        // group the atomics of histogram u+1 are queued before the look-ups of histogram u are consumed, and
+        // the four per-lane sums are reduced together by one transposed butterfly (7 exchanges).
+        // marginals: sum_i T[hx_i] per column
 #pragma unroll 1
-        for (int g = 0; g < 2; ++g) {
-            uint64_t acc[16];
+        for (int c0 = 0; c0 < kNDim; c0 += 4) {
+            uint64_t acc4[4] = {0ull, 0ull, 0ull, 0ull};
+            uint32_t oldA[K], oldB[K];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                acc[i] = 0ull;
-                const int c = g * 16 + i;
-                if (c < kNDim) {
-                    uint32_t w[KW];
-                    load_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, w);
-                    uint64_t a = 0ull;
+            for (int u = 0; u <= 4; ++u) {
+                if (u < 4 && c0 + u < kNDim) { // wave-uniform
+                    uint32_t w[KW], key[K];
+                    col_words(c0 + u, w);
 #pragma unroll
                     for (int kk = 0; kk < K; ++kk)
-                        if (vmask & (1u << kk)) {
-                            const uint32_t old = atomicAdd(&sHist[(w[kk >> 2] >> (8 * (kk & 3))) & 0xffu], 1u);
-                            a += Dl(old);
-                        }
-                    zero_words(sHist, B, lane);
-                    acc[i] = a;
+                        key[kk] = inc[kk] ? ((w[kk >> 2] >> (8 * (kk & 3))) & 0xffu) : hole1;
+                    if (u & 1) issue(key, oldB, B); else issue(key, oldA, B);
                 }
+                if (u >= 1 && c0 + u - 1 < kNDim) acc4[u - 1] = consume(((u - 1) & 1) ? oldB : oldA);
             }
-            const uint64_t tot = reduce16(acc, lane);
-            const int slot = g * 16 + reduce16_slot(lane);
-            if ((lane & 3) == 0 && slot < kNDim) sHXf[slot] = tot;
+            const uint64_t tot = reduce4(acc4, lane);
+            const int c = c0 + reduce4_slot(lane);
+            if ((lane & 15) == 0 && c < kNDim) sHXf[c] = tot;
         }
         // joint histograms, grouped by an anchor column whose (bin * B) stays in registers
         //   anchors 0..3 = r0, r1, p0, p1 with partners f0..f11, c0..c2 ; anchors 4..6 = c0..c2 with f0..f11
 #pragma unroll 1
         for (int g = 0; g < 7; ++g) {
-            const int acol = g < 2 ? kColR + g : (g < 4 ? kColP + (g - 2) : kColC + (g - 4));
             const int np = g < 4 ? 15 : 12;
+            const int acol = g < 2 ? kColR + g : (g < 4 ? kColP + (g - 2) : kColC + (g - 4));
+            const int l = g < 2 ? g : 2 + (g - 2); // r0,r1 -> 0,1 ; p0,p1 -> 2,3
             uint32_t akey[K];
             {
                 uint32_t w[KW];
-                load_words<KW>(sBinW + ((size_t)acol * kWave + lane) * KW, w);
+                col_words(acol, w);
 #pragma unroll
                 for (int kk = 0; kk < K; ++kk) akey[kk] = ((w[kk >> 2] >> (8 * (kk & 3))) & 0xffu) * (uint32_t)B;
             }
-            uint64_t acc[16];
+#pragma unroll 1
+            for (int i0 = 0; i0 < np; i0 += 4) {
+                uint64_t acc4[4] = {0ull, 0ull, 0ull, 0ull};
+                uint32_t oldA[K], oldB[K];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                acc[i] = 0ull;
-                if (i < np) { // wave-uniform
-                    const int bcol = i < 12 ? kColF + i : kColC + (i - 12);
-                    uint32_t w[KW];
-                    load_words<KW>(sBinW + ((size_t)bcol * kWave + lane) * KW, w);
-                    uint64_t a = 0ull;
+                for (int u = 0; u <= 4; ++u) {
+                    if (u < 4 && i0 + u < np) { // wave-uniform
+                        const int i = i0 + u;
+                        uint32_t w[KW], key[K];
+                        col_words(i < 12 ? kColF + i : kColC + (i - 12), w);
 #pragma unroll
-                    for (int kk = 0; kk < K; ++kk)
-                        if (vmask & (1u << kk)) {
-                            const uint32_t key = akey[kk] + ((w[kk >> 2] >> (8 * (kk & 3))) & 0xffu); // mi.cpp:39
-                            const uint32_t old = atomicAdd(&sHist[key], 1u);
-                            a += Dl(old);
-                        }
-                    zero_words(sHist, B * B, lane);
-                    acc[i] = a;
+                        for (int kk = 0; kk < K; ++kk)
+                            key[kk] = inc[kk] ? akey[kk] + ((w[kk >> 2] >> (8 * (kk & 3))) & 0xffu) : hole2; // mi.cpp:39
+                        if (u & 1) issue(key, oldB, ncell2); else issue(key, oldA, ncell2);
+                    }
+                    if (u >= 1 && i0 + u - 1 < np) acc4[u - 1] = consume(((u - 1) & 1) ? oldB : oldA);
                 }
-            }
-            const uint64_t tot = reduce16(acc, lane);
-            const int i = reduce16_slot(lane);
-            if ((lane & 3) == 0 && i < np) {
-                // pair index in ComputeCFWeights call order (rpf.cpp:416-442)
-                int pr;
-                if (g < 4) pr = i < 12 ? i * 4 + (g < 2 ? g : 2 + (g - 2)) : 48 + (i - 12) * 16 + (g < 2 ? g : 2 + (g - 2));
-                else pr = 48 + (g - 4) * 16 + 4 + i;
-                sPairF[pr] = tot;
+                const uint64_t tot = reduce4(acc4, lane);
+                const int i = i0 + reduce4_slot(lane);
+                if ((lane & 15) == 0 && i < np) {
+                    // pair index in ComputeCFWeights call order (rpf.cpp:416-442)
+                    int pr;
+                    if (g < 4) pr = i < 12 ? i * 4 + l : 48 + (i - 12) * 16 + l;
+                    else pr = 48 + (g - 4) * 16 + 4 + i;
+                    sPairF[pr] = tot;
+                }
             }
         }
     }
+#endif
     wsync();
     {
         const int64_t TNf = (int64_t)p.tfix[n];
@@ -565,6 +811,7 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
         }
     }
     bool bad = false;
+#ifndef RPF_X_SKIP4
     for (int i0 = 0; i0 < ((p.stage_mask & 8) ? S : 0); i0 += 8) {
         double sw[8], s0[8], s1[8], s2[8];
 #pragma unroll
@@ -596,27 +843,67 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
                 }
             }
         }
+        // 32 wave sums by two transposed butterflies, gathered through LDS: [0..7] sum w, [8..15] r, [16..23] g, [24..31] b
+        {
+            double ga[16], gb[16];
 #pragma unroll
-        for (int ii = 0; ii < 8; ++ii) {
-            const int i = i0 + ii;
-            if (i < S) { // wave-uniform
-                const double tw = wave_sum(sw[ii]);
-                double c3[3] = {wave_sum(s0[ii]), wave_sum(s1[ii]), wave_sum(s2[ii])};
-                if (lane < 3) {
-                    double prime = (lane == 0 ? c3[0] : (lane == 1 ? c3[1] : c3[2])) / tw; // rpf.cpp:700
-                    if (isnan(prime)) {                     // rpf.cpp:702: the reference exits here
+            for (int ii = 0; ii < 8; ++ii) { ga[ii] = sw[ii]; ga[8 + ii] = s0[ii]; gb[ii] = s1[ii]; gb[8 + ii] = s2[ii]; }
+            const double ta = reduce16_sum(ga, lane), tb = reduce16_sum(gb, lane);
+            wsync();
+            if ((lane & 3) == 0) {
+                sMI[reduce16_slot(lane)] = ta;
+                sMI[16 + reduce16_slot(lane)] = tb;
+            }
+            wsync();
+            if (lane < 24) {
+                const int ii = lane / 3, k = lane % 3;
+                const int i = i0 + ii;
+                if (i < S) {
+                    double prime = sMI[8 * (k + 1) + ii] / sMI[ii];       // rpf.cpp:700
+                    if (isnan(prime)) {                                    // rpf.cpp:702: the reference exits here
                         bad = true;
-                        if (p.policy == RPF_DEGEN_EPS) prime = sOwn[i * kNDim + kColC + lane];
+                        if (p.policy == RPF_DEGEN_EPS) prime = sOwn[i * kNDim + kColC + k];
                     }
-                    p.col_out[(uint64_t)lane * p.plane_stride + pix * S + i] = prime;
+                    p.col_out[(uint64_t)k * p.plane_stride + pix * S + i] = prime;
                 }
             }
         }
     }
+#endif
     if (__any(bad) && lane == 0) {
         atomicAdd(&p.status[0], 1);
         atomicMin(&p.status[1], (int)pix);
     }
+}
+
+// self-test of udiv(): bitwise comparison with the compiler's IEEE division on pseudo-random operands
+// drawn from the magnitudes stage 3a sees (and a band of extreme ones that must take the fallback)
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void udiv_selftest_kernel(uint64_t n, uint64_t seed, int mode,
+                                                             unsigned long long *mismatch) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long bad = 0;
+    for (; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t h1 = mix64(seed + 2 * i), h2 = mix64(seed + 2 * i + 1);
+        // mantissas: random 52 bits; exponents: mode 0 -> [-40, 40], mode 1 -> [-600, 600] (hits the fallback)
+        const int span = mode == 0 ? 81 : 1201;
+        const int ea = (int)((h1 >> 52) % span) - span / 2, eb = (int)((h2 >> 52) % span) - span / 2;
+        double a = ldexp(1.0 + (double)(h1 & 0xFFFFFFFFFFFFFull) * 0x1p-52, ea);
+        double b = ldexp(1.0 + (double)(h2 & 0xFFFFFFFFFFFFFull) * 0x1p-52, eb);
+        if (h1 & (1ull << 63)) a = -a;
+        if ((h2 >> 60) == 0) a = (double)(float)a;          // fp32-valued numerators, as the feature planes are
+        if ((h2 >> 60) == 1) a = b * (double)(int)(h1 % 41); // exact quotients (bin edges)
+        if ((h2 >> 60) == 2) a = 0.0;
+        const UDiv d = udiv_prepare(b);
+        const double q = udiv(a, d), want = a / b;
+        if (__double_as_longlong(q) != __double_as_longlong(want)) ++bad;
+    }
+    if (bad) atomicAdd(mismatch, bad);
 }
 
 __global__ __launch_bounds__(256) void colour_from_planes_kernel(const float *planes, double *colour, uint64_t ps) {
@@ -707,7 +994,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     uint32_t o = 0;
     L.off_T = o;
     if (t_in_lds) o += align_up((uint32_t)nmax * 8u, 16);
-    L.off_stat = o; o += align_up(2 * kNDim * 8, 16);
+    L.off_stat = o; o += align_up(4 * kNDim * 8, 16);
     L.off_hx = o; o += align_up(kNDim * 8, 16);
     L.off_pair = o; o += align_up(kNPair * 8, 16);
     L.off_mi = o; o += align_up(kNPair * 8, 16);
@@ -716,15 +1003,19 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     L.off_union = o;
     const uint32_t stage = align_up(kNDim * (kStageChunk + 1) * 8, 16);
     const uint32_t bins = align_up((uint32_t)kNDim * kWave * KW * 4u, 16);
-    L.off_hist = o + bins;
-    const uint32_t hist = align_up((uint32_t)bmax * (uint32_t)bmax * 4u, 16);
-    const uint32_t uni = (bins + hist) > stage ? (bins + hist) : stage;
-    o += uni;
+    o += bins > stage ? bins : stage;
+    L.off_hist = o;
+    o += align_up((uint32_t)bmax * (uint32_t)bmax * 4u, 16);
     L.total = o;
     return L;
 }
 
 int max_lds_per_block() { return 160 * 1024; }
+
+hipError_t launch_udiv_selftest(uint64_t n, uint64_t seed, int mode, unsigned long long *d_mismatch, hipStream_t s) {
+    hipLaunchKernelGGL(udiv_selftest_kernel, dim3(2048), dim3(256), 0, s, n, seed, mode, d_mismatch);
+    return hipGetLastError();
+}
 
 hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s) {
     const uint64_t HW = (uint64_t)p.H * p.W;

@@ -21,7 +21,7 @@ FLAG_TIMING = 1
 
 EXPORTS = ["rpf_version", "rpf_status_string", "rpf_create", "rpf_destroy", "rpf_last_error", "rpf_filter",
            "rpf_filter_device", "rpf_colour_from_planes_device", "rpf_reduce_device", "rpf_stage_pixel_stats",
-           "rpf_filter_pass_debug", "rpf_query_counters", "rpf_lds_bytes_required"]
+           "rpf_filter_pass_debug", "rpf_query_counters", "rpf_lds_bytes_required", "rpf_selftest_udiv"]
 
 
 class Desc(C.Structure):
@@ -77,6 +77,7 @@ def load():
         L.rpf_filter_pass_debug.argtypes = [C.c_void_p, C.POINTER(Desc), C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.POINTER(Debug)]
         L.rpf_query_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+        L.rpf_selftest_udiv.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_uint64)]
         L.rpf_lds_bytes_required.restype = C.c_int64
         L.rpf_lds_bytes_required.argtypes = [C.c_int32, C.c_int32]
         _lib = L
@@ -180,6 +181,11 @@ class Context:
         d.update(colour=out, status=st, nonfinite_pixels=c.nonfinite_pixels, first_bad_pixel=c.first_bad_pixel,
                  sum_nbhd=c.sum_nbhd, max_nbhd=c.max_nbhd, filter_kernel_ms=c.filter_kernel_ms)
         return d
+
+    def selftest_udiv(self, n, seed=1, mode=0):
+        m = C.c_uint64(0)
+        self._check(self._L.rpf_selftest_udiv(self._h, n, seed, mode, C.byref(m)))
+        return m.value
 
     # ---- device-resident entry points (raw device pointers) -----------------------------------------
     def colour_from_planes_device(self, desc, d_planes, d_colour, stream=None):

@@ -36,6 +36,12 @@ def check_pass(got, want, rows=None, ab_rtol=1e-9):
     return r
 
 
+def test_uniform_divisor_division_is_exact(ctx):
+    """stage 3a divides by per-column constants with a hoisted reciprocal; it must equal IEEE a/b bit for bit"""
+    assert ctx.selftest_udiv(200_000_000, seed=1, mode=0) == 0
+    assert ctx.selftest_udiv(50_000_000, seed=2, mode=1) == 0
+
+
 def test_stage1a_pixel_stats_bit_exact(ctx, hipmod, oracle):
     W, H, S = 37, 21, 8
     planes = fb.synth_planes(W, H, S, seed=3)
