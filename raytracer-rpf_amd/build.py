@@ -35,5 +35,27 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HOST_LIB = os.path.join(_HERE, "lib", "librpf_host.so")
+HOST_SOURCES = [os.path.join(_HERE, "host", "rpf_host.cpp")]
+HOST_HEADERS = [os.path.join(_HERE, "host", "rpf_host.h"), os.path.join(_ROOT, "include", "rpf_hip.h")]
+
+
+def build_host(force=False, verbose=False):
+    """host-side C++ mirror of the reference interface (g++, no HIP), linked against librpf_hip.so"""
+    build(force=False)
+    stale = (not os.path.exists(HOST_LIB)) or any(
+        os.path.getmtime(f) > os.path.getmtime(HOST_LIB) for f in HOST_SOURCES + HOST_HEADERS + [LIB])
+    if not force and not stale:
+        return HOST_LIB
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-I" + os.path.join(_ROOT, "include"),
+           "-I" + os.path.join(_HERE, "host"), "-o", HOST_LIB] + HOST_SOURCES + [
+           "-L" + os.path.dirname(LIB), "-lrpf_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
+    print(build_host(force=True, verbose=True))
     print(build(force=True, verbose=True))

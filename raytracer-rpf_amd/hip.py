@@ -60,6 +60,13 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise OSError("librpf_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`. "
                           "There is no CPU fallback." % LIB_PATH)
+        try:
+            # PyTorch wheels bundle their own HIP runtime; when torch is used in the same process (HBM tensors,
+            # streams, torch.distributed) it must be the first to load libamdhip64 so that both sides share ONE
+            # runtime -- loading ours first leaves torch unable to see the GPU.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.rpf_version.restype = C.c_char_p
         L.rpf_status_string.restype = C.c_char_p

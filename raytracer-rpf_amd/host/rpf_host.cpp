@@ -1,0 +1,127 @@
+// rpf_host.cpp -- see rpf_host.h.  Plain C++ (no HIP): everything device-side happens behind the C ABI.
+#include "rpf_host.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace rpf_host {
+
+RPFFilter::RPFFilter(int device) {
+    const int32_t st = rpf_create(&ctx_, device);
+    if (st != RPF_OK) {
+        err_ = std::string(rpf_status_string(st)) + ": " + (ctx_ ? rpf_last_error(ctx_) : "no HIP device");
+        if (ctx_) rpf_destroy(ctx_);
+        ctx_ = nullptr;
+    }
+}
+
+RPFFilter::~RPFFilter() {
+    if (ctx_) rpf_destroy(ctx_);
+}
+
+int RPFFilter::ApplyRPFFilter(SamplingFilm &film, const int /*tileSize*/, int box_size) {
+    return run(film, std::vector<int>{box_size}, nullptr);
+}
+
+int RPFFilter::FilterAndReduce(SamplingFilm &film, const std::vector<int> &boxes, std::vector<float> *pixel_rgb) {
+    return run(film, boxes, pixel_rgb);
+}
+
+int RPFFilter::run(SamplingFilm &film, const std::vector<int> &boxes, std::vector<float> *pixel_rgb) {
+    if (!ctx_) return RPF_E_NODEVICE; // constructor failed; err_ says why.  There is no CPU fallback.
+    const int W = film.getWidth(), H = film.getHeight();
+    if (W <= 0 || H <= 0) { err_ = "empty SamplingFilm"; return RPF_E_BADARG; }
+    const size_t S = film.samples[0][0].size();
+    if (S == 0) { err_ = "pixel (0,0) has no samples"; return RPF_E_BADARG; }
+    // the reference silently assumes every pixel holds the same number of samples (getMean on an empty
+    // vector otherwise, ops.h:116); the ABI makes it a checked precondition
+    for (int x = 0; x < W; ++x)
+        for (int y = 0; y < H; ++y)
+            if (film.samples[x][y].size() != S) {
+                char b[128];
+                std::snprintf(b, sizeof(b), "pixel (%d,%d) holds %zu samples, expected %zu", x + film.x0, y + film.y0,
+                              film.samples[x][y].size(), S);
+                err_ = b;
+                return RPF_E_BADARG;
+            }
+    if (boxes.empty() || boxes.size() > RPF_MAX_BOXES) { err_ = "1..8 box sizes"; return RPF_E_BADARG; }
+
+    // marshal AoS doubles [x][y][s][19] -> SoA fp32 planes [19][y][x][s] (values are fp32-valued: pbrt Float)
+    const size_t ps = (size_t)W * H * S;
+    planes_.resize(RPF_NDIM * ps);
+    rayw_.resize(ps);
+    srgb_.resize(3 * ps);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const SampleDataSet &px = film.samples[x][y];
+            const size_t base = ((size_t)y * W + x) * S;
+            for (size_t s = 0; s < S; ++s) {
+                for (int d = 0; d < RPF_NDIM; ++d) planes_[(size_t)d * ps + base + s] = (float)px[s].data[d];
+                rayw_[base + s] = px[s].rayWeight;
+            }
+        }
+
+    rpf_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.W = W; d.H = H; d.S = (int32_t)S;
+    d.row_begin = 0; d.row_end = H;
+    d.n_box = (int32_t)boxes.size();
+    for (size_t i = 0; i < boxes.size(); ++i) d.box_sizes[i] = boxes[i];
+    d.beta_map = beta_map; d.degenerate_policy = degenerate_policy;
+    d.eps = eps; d.sigma_seed = sigma_seed;
+    d.flags = RPF_FLAG_TIMING;
+    if (pixel_rgb) pixel_rgb->resize((size_t)W * H * 3);
+    const int32_t st = rpf_filter(ctx_, &d, planes_.data(), rayw_.data(), srgb_.data(), pixel_rgb ? pixel_rgb->data() : nullptr);
+    rpf_query_counters(ctx_, &counters_);
+    if (st != RPF_OK) err_ = std::string(rpf_status_string(st)) + ": " + rpf_last_error(ctx_);
+    if (st != RPF_OK && st != RPF_E_NONFINITE) return st;
+
+    // write the filtered colours back into the film (rpf.cpp:715, 732); other columns untouched
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            SampleDataSet &px = film.samples[x][y];
+            const size_t base = ((size_t)y * W + x) * S;
+            for (size_t s = 0; s < S; ++s)
+                for (int c = 0; c < 3; ++c) px[s].setColorI(c, (double)srgb_[(size_t)c * ps + base + s]);
+        }
+    return st;
+}
+
+} // namespace rpf_host
+
+extern "C" int32_t rpf_host_apply_filter_aos(double *aos, const float *ray_weight, int32_t W, int32_t H, int32_t S,
+                                             const int32_t *box_sizes, int32_t n_box, int32_t beta_map, int32_t policy,
+                                             int32_t device, float *pixel_rgb_out, char *err, int32_t err_len) {
+    using namespace rpf_host;
+    if (!aos || !box_sizes || W <= 0 || H <= 0 || S <= 0) return RPF_E_BADARG;
+    SamplingFilm film(W, H);
+    for (int x = 0; x < W; ++x)
+        for (int y = 0; y < H; ++y) {
+            SampleDataSet &px = film.samples[x][y];
+            px.resize(S);
+            for (int s = 0; s < S; ++s) {
+                const size_t o = (((size_t)x * H + y) * S + s);
+                std::memcpy(px[s].data, aos + o * RPF_NDIM, sizeof(double) * RPF_NDIM);
+                px[s].rayWeight = ray_weight ? ray_weight[o] : 1.0f;
+            }
+        }
+    RPFFilter f(device);
+    f.beta_map = beta_map;
+    f.degenerate_policy = policy;
+    std::vector<float> pix;
+    int st;
+    if (n_box == 1 && !pixel_rgb_out) st = f.ApplyRPFFilter(film, 16, box_sizes[0]);
+    else st = f.FilterAndReduce(film, std::vector<int>(box_sizes, box_sizes + n_box), pixel_rgb_out ? &pix : nullptr);
+    if (err && err_len > 0) std::snprintf(err, err_len, "%s", f.last_error().c_str());
+    if (st != RPF_OK && st != RPF_E_NONFINITE) return st;
+    for (int x = 0; x < W; ++x)
+        for (int y = 0; y < H; ++y)
+            for (int s = 0; s < S; ++s) {
+                const size_t o = (((size_t)x * H + y) * S + s);
+                std::memcpy(aos + o * RPF_NDIM, film.samples[x][y][s].data, sizeof(double) * RPF_NDIM);
+            }
+    if (pixel_rgb_out) std::memcpy(pixel_rgb_out, pix.data(), pix.size() * sizeof(float));
+    return st;
+}

@@ -1,0 +1,85 @@
+// rpf_host.h -- host-side mirror (C++) of the reference's interface for the hot path, above the C ABI.
+//
+// The reference is compiled C++ with no plugin ABI: RPFIntegrator::Render (rpf.cpp:737-805) owns a
+// SamplingFilm (sample_film.h:28-45: samples[x][y] = std::vector<SampleData>, SampleData = 19 doubles +
+// Float rayWeight, sd.h:51-60) and calls the private member
+//     void ApplyRPFFilter(SamplingFilm &samplingFilm, const int tileSize, int box_size)   (rpf.h:91-95)
+// once per box size.  This header reproduces those shapes without any pbrt type so that the call site reads
+// the same; the body marshals AoS doubles -> SoA fp32 planes and calls librpf_hip.so.  A pbrt maintainer
+// keeps pbrt's own SampleData/SamplingFilm and only copies the body of RPFFilter::ApplyRPFFilter (see
+// INTEGRATION.md).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rpf_hip.h"
+
+namespace rpf_host {
+
+constexpr int SD_N_FEATURES = 12, SD_N_POSITION = 2, SD_N_RANDOM = 2, SD_N_COLOR = 3; // sd.h:40-43
+
+// same field order and meaning as pbrt::SampleData (sd.h:51-60); the getters the filter path uses
+struct SampleData {
+    double data[RPF_NDIM];
+    float rayWeight;
+    double getColorI(int i) const { return data[2 + i]; }      // sd.h:205
+    void setColorI(int i, double v) { data[2 + i] = v; }       // sd.h:208
+    double getFeatureI(int i) const { return data[7 + i]; }    // sd.h:155
+};
+typedef std::vector<SampleData> SampleDataSet;                 // sd.h:239
+
+// same container as pbrt::SamplingFilm (sample_film.h:28-45): x-major, samples[x - x0][y - y0]
+struct SamplingFilm {
+    std::vector<std::vector<SampleDataSet>> samples;
+    int x0 = 0, y0 = 0; // pixelBounds.pMin
+    SamplingFilm(int width, int height, int x0_ = 0, int y0_ = 0)
+        : samples(width, std::vector<SampleDataSet>(height)), x0(x0_), y0(y0_) {}
+    int getWidth() const { return (int)samples.size(); }                       // sample_film.cpp:68
+    int getHeight() const { return samples.empty() ? 0 : (int)samples[0].size(); } // sample_film.cpp:72
+    void AddSample(int px, int py, const SampleData &s) { samples[px - x0][py - y0].push_back(s); } // sample_film.cpp:44
+};
+
+class RPFFilter {
+  public:
+    explicit RPFFilter(int device = 0);
+    ~RPFFilter();
+    RPFFilter(const RPFFilter &) = delete;
+    RPFFilter &operator=(const RPFFilter &) = delete;
+
+    // the reference hard-codes these (rpf.cpp:533, 767); defaults reproduce it
+    int beta_map = RPF_BETA_REF_GCC11_O3;
+    int degenerate_policy = RPF_DEGEN_REF_ABORT;
+    double eps = 1e-10, sigma_seed = 0.002;
+
+    // Drop-in for RPFIntegrator::ApplyRPFFilter (rpf.cpp:497-733): on return the colour columns (data[2..4]) of
+    // every sample hold the filtered colours, everything else is untouched (rpf.cpp:715, 732).  tileSize is
+    // accepted for signature compatibility (the GPU path does not tile on the host).  Returns an rpf_status;
+    // where the reference prints "PRIME ERROR" and calls exit(1) (rpf.cpp:702-705) this returns
+    // RPF_E_NONFINITE and leaves the NaNs in place for the caller to report.
+    int ApplyRPFFilter(SamplingFilm &samplingFilm, const int tileSize, int box_size);
+
+    // The whole post-sampling part of Render(): every box size (rpf.cpp:767-775) and the film reduction with
+    // the default box reconstruction filter (rpf.cpp:779-794): pixel_rgb[(y*W+x)*3+c], may be NULL.
+    int FilterAndReduce(SamplingFilm &samplingFilm, const std::vector<int> &box_sizes, std::vector<float> *pixel_rgb);
+
+    const std::string &last_error() const { return err_; }
+    const rpf_counters &counters() const { return counters_; }
+
+  private:
+    int run(SamplingFilm &film, const std::vector<int> &boxes, std::vector<float> *pixel_rgb);
+    rpf_ctx *ctx_ = nullptr;
+    std::string err_;
+    rpf_counters counters_{};
+    std::vector<float> planes_, rayw_, srgb_;
+};
+
+} // namespace rpf_host
+
+extern "C" {
+// test / FFI doorway: aos is double [W][H][S][19] in SamplingFilm order, ray_weight float [W][H][S] (may be NULL);
+// colours are filtered in place.  Returns an rpf_status.
+int32_t rpf_host_apply_filter_aos(double *aos, const float *ray_weight, int32_t W, int32_t H, int32_t S,
+                                  const int32_t *box_sizes, int32_t n_box, int32_t beta_map, int32_t policy,
+                                  int32_t device, float *pixel_rgb_out, char *err, int32_t err_len);
+}

@@ -156,3 +156,89 @@ def test_badarg_and_unsupported(ctx, hipmod):
     with pytest.raises(hipmod.RpfError) as e:
         ctx.filter(planes, hipmod.make_desc(4, 4, 2, boxes=(55,)))
     assert e.value.status == hipmod.E_UNSUPPORTED
+
+
+# ---- committed fixtures, host mirror, full-size properties -------------------------------------------
+import ctypes as C  # noqa: E402
+import os  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", ["e2e_clustered_12x10x8_box7", "e2e_smooth_10x8x8_box7",
+                                  "e2e_clustered_8x6x16_box5", "e2e_constnormal_8x6x8_box7_eps"])
+def test_gpu_reproduces_committed_fixtures(ctx, hipmod, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    planes = g["planes"]
+    _, H, W, S = planes.shape
+    got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, policy=int(g["policy"])), box=int(g["box"]))
+    want = {k: g[k] for k in ("nbhd_size", "member_hash", "bin_hash", "mean", "stddev", "mi", "alpha", "beta", "wrc", "colour")}
+    check_pass(got, want, ab_rtol=5e-3 if "eps" in name else 1e-9)
+    assert got["nonfinite_pixels"] == int(g["nonfinite_pixels"])
+
+
+def test_host_mirror_apply_rpf_filter(hipmod, oracle):
+    """the C++ mirror of RPFIntegrator::ApplyRPFFilter(SamplingFilm&, tileSize, box_size): AoS doubles in
+    SamplingFilm order in, colour columns replaced, every other column untouched (rpf.cpp:715, 732)"""
+    lib = C.CDLL(os.path.join(os.path.dirname(hipmod.LIB_PATH), "librpf_host.so"))
+    W, H, S = 14, 9, 8
+    planes = fb.synth_planes(W, H, S, seed=6, sigma_f=1e-3, sigma_c=0.01, mode="clustered")
+    aos = fb.planes_to_aos(planes)
+    before = aos.copy()
+    boxes = (C.c_int32 * 1)(7)
+    err = C.create_string_buffer(256)
+    st = lib.rpf_host_apply_filter_aos(aos.ctypes.data_as(C.c_void_p), None, W, H, S, boxes, 1, 0, 0, 0, None, err, 256)
+    assert st == 0, err.value
+    want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7), debug=False)["colour"]
+    got = np.transpose(aos[..., 2:5], (3, 1, 0, 2))  # [x][y][s][c] -> [c][y][x][s]
+    assert rel_l2(got, want) <= REL_L2_BAR
+    keep = [0, 1] + list(range(5, 19))
+    assert np.array_equal(aos[..., keep], before[..., keep])
+    assert rel_l2(got, planes[2:5].astype(np.float64)) > 1e-3  # and the filter did something
+
+
+def test_full_size_1080p_properties(ctx, hipmod, oracle):
+    """BASELINE configs[1] (1920x1080x8spp) through size-independent properties: determinism, neighbourhood
+    size bounds, convex-combination bounds of every filtered colour, slab == full frame on a band, and the
+    oracle on a few full-width rows."""
+    import torch
+    W, H, S, b = 1920, 1080, 8, 3
+    dev = torch.device("cuda", 0)
+    planes = fb.synth_planes(W, H, S, xp=fb.torch_backend(dev), mode="clustered", sigma_f=1e-3, sigma_c=0.01).contiguous()
+    col0 = planes[2:5].to(torch.float64).contiguous()
+    desc = hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS)
+    outs = []
+    for _ in range(2):
+        c = col0.clone()
+        ctx.filter_device(desc, planes.data_ptr(), c.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        outs.append(c)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])                     # bitwise reproducible (integer histogram sums)
+    cnt = ctx.counters()
+    assert cnt.nonfinite_pixels == 0 and S <= cnt.max_nbhd <= 49 * S
+    assert S * W * H <= cnt.sum_nbhd <= 49 * S * W * H
+    # every filtered colour is a convex combination of colours inside its 7x7 window
+    pad = torch.nn.functional.pad
+    cmin = col0.amin(dim=3)
+    cmax = col0.amax(dim=3)
+    wmin = -torch.nn.functional.max_pool2d(pad(-cmin, (b, b, b, b), value=-1e30), 2 * b + 1, stride=1)
+    wmax = torch.nn.functional.max_pool2d(pad(cmax, (b, b, b, b), value=-1e30), 2 * b + 1, stride=1)
+    out = outs[0]
+    tol = 1e-9
+    assert bool((out >= wmin[..., None] - tol).all()) and bool((out <= wmax[..., None] + tol).all())
+    # a 64-row slab with halo reproduces the same rows
+    a0, a1 = 500, 564
+    sub = planes[:, a0 - b:a1 + b].contiguous()
+    csub = sub[2:5].to(torch.float64).contiguous()
+    d2 = hipmod.make_desc(W, a1 - a0 + 2 * b, S, row_begin=b, row_end=b + a1 - a0, policy=hipmod.DEGEN_EPS)
+    ctx.filter_device(d2, sub.data_ptr(), csub.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(csub[:, b:b + a1 - a0], out[:, a0:a1])
+    # and the oracle agrees on 3 full-width rows of it
+    R = 3
+    host = sub[:, :2 * b + R].cpu().numpy()
+    want = oracle.filter_pass(host, oracle.make_desc(W, 2 * b + R, S, box=7, row_begin=b, row_end=b + R,
+                                                     policy=oracle.DEGEN_EPS), debug=False)["colour"][:, b:b + R]
+    got = out[:, a0:a0 + R].cpu().numpy()
+    assert rel_l2(got, want) <= REL_L2_BAR
+    assert rel_l2(got, host[2:5, b:b + R].astype(np.float64)) > 1e-3
