@@ -23,8 +23,10 @@
 //       shuffle reductions.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cstdlib>
 
 #include "rpf_internal.h"
+#include "rpf_xlane.h"
 
 namespace rpf {
 
@@ -54,22 +56,6 @@ __constant__ PairTable c_pairs = make_pairs();
 
 // the workgroup is exactly one wavefront: the barrier is an LDS/memory ordering point, not a rendezvous
 __device__ __forceinline__ void wsync() { __syncthreads(); }
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 64));
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
-    return v;
-}
 
 __device__ __forceinline__ uint32_t fnv1a_u32(uint32_t h, uint32_t v) {
 #pragma unroll
@@ -119,71 +105,6 @@ __device__ __forceinline__ void store_words(uint32_t *dst, const uint32_t (&w)[K
 // clear `cells` 32-bit histogram cells (buffer is 16-byte aligned and padded to a multiple of 4 cells)
 __device__ __forceinline__ void zero_words(uint32_t *h, int cells, int lane) {
     for (int t = lane * 4; t < cells; t += kWave * 4) *reinterpret_cast<uint4 *>(h + t) = make_uint4(0u, 0u, 0u, 0u);
-}
-
-// Sum 16 per-lane accumulators over the 64 lanes with a transposed butterfly (17 exchanges instead of
-// 16 x 6): afterwards every lane holds the wave total of accumulator reduce16_slot(lane).
-__device__ __forceinline__ int reduce16_slot(int lane) {
-    return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-}
-__device__ __forceinline__ uint64_t reduce16(const uint64_t (&a)[16], int lane) {
-    uint64_t b8[8], b4[4], b2[2];
-    {
-        const bool up = (lane & 32) != 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint64_t keep = up ? a[i + 8] : a[i], send = up ? a[i] : a[i + 8];
-            b8[i] = keep + (uint64_t)__shfl_xor((unsigned long long)send, 32, 64);
-        }
-    }
-    {
-        const bool up = (lane & 16) != 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint64_t keep = up ? b8[i + 4] : b8[i], send = up ? b8[i] : b8[i + 4];
-            b4[i] = keep + (uint64_t)__shfl_xor((unsigned long long)send, 16, 64);
-        }
-    }
-    {
-        const bool up = (lane & 8) != 0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const uint64_t keep = up ? b4[i + 2] : b4[i], send = up ? b4[i] : b4[i + 2];
-            b2[i] = keep + (uint64_t)__shfl_xor((unsigned long long)send, 8, 64);
-        }
-    }
-    uint64_t v;
-    {
-        const bool up = (lane & 4) != 0;
-        const uint64_t keep = up ? b2[1] : b2[0], send = up ? b2[0] : b2[1];
-        v = keep + (uint64_t)__shfl_xor((unsigned long long)send, 4, 64);
-    }
-    v += (uint64_t)__shfl_xor((unsigned long long)v, 2, 64);
-    v += (uint64_t)__shfl_xor((unsigned long long)v, 1, 64);
-    return v;
-}
-
-// 4 accumulators per lane -> wave totals; afterwards a lane holds the total of accumulator reduce4_slot(lane)
-__device__ __forceinline__ int reduce4_slot(int lane) { return ((lane >> 5) & 1) * 2 + ((lane >> 4) & 1); }
-__device__ __forceinline__ uint64_t reduce4(const uint64_t (&a)[4], int lane) {
-    uint64_t b2[2];
-    {
-        const bool up = (lane & 32) != 0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const uint64_t keep = up ? a[i + 2] : a[i], send = up ? a[i] : a[i + 2];
-            b2[i] = keep + (uint64_t)__shfl_xor((unsigned long long)send, 32, 64);
-        }
-    }
-    uint64_t v;
-    {
-        const bool up = (lane & 16) != 0;
-        const uint64_t keep = up ? b2[1] : b2[0], send = up ? b2[0] : b2[1];
-        v = keep + (uint64_t)__shfl_xor((unsigned long long)send, 16, 64);
-    }
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, m, 64);
-    return v;
 }
 
 // value of column c of the sample at plane offset `off`: colours come from the fp64 colour planes
@@ -257,91 +178,124 @@ __device__ __forceinline__ double udiv(double a, const UDiv &d) {
     return ok ? udiv_fast(a, d) : a / d.b;
 }
 
-// 32 floats per lane -> per-slot minimum over the wave (transposed butterfly, 32 exchanges); afterwards a
-// lane holds the minimum of slot ((lane>>1) & 31)
-__device__ __forceinline__ float reduce32_min(float (&a)[32], int lane) {
-    float b16[16], b8[8], b4[4], b2[2];
-    {
-        const bool up = (lane & 32) != 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float keep = up ? a[i + 16] : a[i], send = up ? a[i] : a[i + 16];
-            b16[i] = fminf(keep, __shfl_xor(send, 32, 64));
-        }
-    }
-    {
-        const bool up = (lane & 16) != 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float keep = up ? b16[i + 8] : b16[i], send = up ? b16[i] : b16[i + 8];
-            b8[i] = fminf(keep, __shfl_xor(send, 16, 64));
-        }
-    }
-    {
-        const bool up = (lane & 8) != 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float keep = up ? b8[i + 4] : b8[i], send = up ? b8[i] : b8[i + 4];
-            b4[i] = fminf(keep, __shfl_xor(send, 8, 64));
-        }
-    }
-    {
-        const bool up = (lane & 4) != 0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float keep = up ? b4[i + 2] : b4[i], send = up ? b4[i] : b4[i + 2];
-            b2[i] = fminf(keep, __shfl_xor(send, 4, 64));
-        }
-    }
-    float v;
-    {
-        const bool up = (lane & 2) != 0;
-        const float keep = up ? b2[1] : b2[0], send = up ? b2[0] : b2[1];
-        v = fminf(keep, __shfl_xor(send, 2, 64));
-    }
-    v = fminf(v, __shfl_xor(v, 1, 64));
-    return v;
+// ---- stage 3b: histograms -> mutual information (mi.cpp:45-90) ------------------------------------------
+// mi.cpp:79-86 over integer counts:  N*MI = T[N] + sum_ij T[J_ij] - sum_i T[hx_i] - sum_j T[hy_j],  T[k] = k ln k.
+// T is tabulated in 2^-44 fixed point, so every sum is an exact integer sum: the result does not depend on the
+// order in which lanes hit a cell, a single-bin column gives exactly MI == 0 like the reference (pX == 1 =>
+// every log term is log(1)), and no log is evaluated on the device.
+// Each increment is a returning LDS atomic; the old count c contributes D[c] = T[c+1]-T[c], which telescopes
+// to T[J] per cell.  The histogram is cleared by wide stores queued right behind the atomics (one wave's LDS
+// operations execute in order).  Histograms are processed four at a time: the atomics of histogram u+1 are
+// queued before the D look-ups of histogram u are consumed, and the four per-lane sums are reduced together by
+// one transposed butterfly (no LDS).  KD = number of occupied sample slots of this pixel (compile time).
+__device__ __forceinline__ void zero_cells(uint32_t *h, int cells, int lane) {
+    // cells <= 512 in the common (K <= 8) case: two predicated 16-byte stores, no loop
+    if (lane * 4 < cells) *reinterpret_cast<uint4 *>(h + lane * 4) = make_uint4(0u, 0u, 0u, 0u);
+    if (lane * 4 + 256 < cells) *reinterpret_cast<uint4 *>(h + lane * 4 + 256) = make_uint4(0u, 0u, 0u, 0u);
+    for (int t = lane * 4 + 512; t < cells; t += kWave * 4) *reinterpret_cast<uint4 *>(h + t) = make_uint4(0u, 0u, 0u, 0u);
 }
-__device__ __forceinline__ int reduce32_slot(int lane) { return (lane >> 1) & 31; }
-// where slot s of reduce32 ends up: lanes with ((lane>>1)&31) == s, e.g. lane 2*s
-// (bit order: slot bit4 <- lane bit5, bit3 <- lane bit4, ... bit0 <- lane bit1)
 
-// 16 doubles per lane -> per-slot wave sums (same butterfly as reduce16 on doubles)
-__device__ __forceinline__ double reduce16_sum(const double (&a)[16], int lane) {
-    double b8[8], b4[4], b2[2];
-    {
-        const bool up = (lane & 32) != 0;
+template <int KD, int KW>
+__device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, uint64_t *sHXf,
+                                         uint64_t *sPairF, int lane, int n, int B) {
+    const int ncell2 = B * B;
+    uint32_t inc[KD]; // 1 for an existing sample, 0 for a hole in the last slot
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const double keep = up ? a[i + 8] : a[i], send = up ? a[i] : a[i + 8];
-            b8[i] = keep + __shfl_xor(send, 32, 64);
+    for (int kk = 0; kk < KD; ++kk) inc[kk] = (lane + kWave * kk < n) ? 1u : 0u;
+    const uint32_t hole1 = (uint32_t)min(lane, B - 1);      // harmless, spread-out targets of the +0 atomics
+    const uint32_t hole2 = (uint32_t)min(lane, ncell2 - 1);
+    zero_cells(sHist, ncell2, lane);
+
+    auto byte_of = [](const uint32_t (&w)[KW], int kk) -> uint32_t { return (w[kk >> 2] >> (8 * (kk & 3))) & 0xffu; };
+
+    // ---- marginals: sum_i T[hx_i] per column, four columns per group (the 20th slot repeats column 18 with +0)
+#pragma unroll 1
+    for (int c0 = 0; c0 < kNDim; c0 += 4) {
+        uint64_t acc4[4];
+        uint32_t old[2][KD];
+#pragma unroll
+        for (int u = 0; u <= 4; ++u) {
+            if (u < 4) {
+                const int c = min(c0 + u, kNDim - 1);
+                const bool live = (c0 + u) < kNDim;
+                uint32_t w[KW];
+                load_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, w);
+#pragma unroll
+                for (int kk = 0; kk < KD; ++kk) {
+                    const bool on = live && inc[kk];
+                    old[u & 1][kk] = atomicAdd(&sHist[on ? byte_of(w, kk) : hole1], on ? 1u : 0u);
+                }
+                zero_cells(sHist, B, lane);
+            }
+            if (u >= 1) {
+                const bool live = (c0 + u - 1) < kNDim;
+                uint64_t d[KD];
+#pragma unroll
+                for (int kk = 0; kk < KD; ++kk) d[kk] = dtab[old[(u - 1) & 1][kk]];
+                uint64_t a = 0ull;
+#pragma unroll
+                for (int kk = 0; kk < KD; ++kk) a += (live && inc[kk]) ? d[kk] : 0ull;
+                acc4[u - 1] = a;
+            }
+        }
+        const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
+        const int c = c0 + xl::slot4(lane);
+        if ((lane & 15) == 0 && c < kNDim) sHXf[c] = tot;
+    }
+    // ---- joint histograms, grouped by an anchor column whose (bin * B) stays in registers
+    //   anchors 0..3 = r0, r1, p0, p1 with partners f0..f11, c0..c2 ; anchors 4..6 = c0..c2 with f0..f11
+#pragma unroll 1
+    for (int g = 0; g < 7; ++g) {
+        const int np = g < 4 ? 15 : 12;
+        const int acol = g < 2 ? kColR + g : (g < 4 ? kColP + (g - 2) : kColC + (g - 4));
+        const int l = g < 2 ? g : 2 + (g - 2); // r0,r1 -> 0,1 ; p0,p1 -> 2,3
+        uint32_t akey[KD];
+        {
+            uint32_t w[KW];
+            load_words<KW>(sBinW + ((size_t)acol * kWave + lane) * KW, w);
+#pragma unroll
+            for (int kk = 0; kk < KD; ++kk) akey[kk] = byte_of(w, kk) * (uint32_t)B;
+        }
+#pragma unroll 1
+        for (int i0 = 0; i0 < np; i0 += 4) {
+            uint64_t acc4[4];
+            uint32_t old[2][KD];
+#pragma unroll
+            for (int u = 0; u <= 4; ++u) {
+                if (u < 4) {
+                    const int i = min(i0 + u, np - 1);
+                    const bool live = (i0 + u) < np;
+                    uint32_t w[KW];
+                    load_words<KW>(sBinW + ((size_t)(i < 12 ? kColF + i : kColC + (i - 12)) * kWave + lane) * KW, w);
+#pragma unroll
+                    for (int kk = 0; kk < KD; ++kk) {
+                        const bool on = live && inc[kk];
+                        old[u & 1][kk] = atomicAdd(&sHist[on ? akey[kk] + byte_of(w, kk) : hole2], on ? 1u : 0u); // mi.cpp:39
+                    }
+                    zero_cells(sHist, ncell2, lane);
+                }
+                if (u >= 1) {
+                    const bool live = (i0 + u - 1) < np;
+                    uint64_t d[KD];
+#pragma unroll
+                    for (int kk = 0; kk < KD; ++kk) d[kk] = dtab[old[(u - 1) & 1][kk]];
+                    uint64_t a = 0ull;
+#pragma unroll
+                    for (int kk = 0; kk < KD; ++kk) a += (live && inc[kk]) ? d[kk] : 0ull;
+                    acc4[u - 1] = a;
+                }
+            }
+            const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
+            const int i = i0 + xl::slot4(lane);
+            if ((lane & 15) == 0 && i < np) {
+                // pair index in ComputeCFWeights call order (rpf.cpp:416-442)
+                int pr;
+                if (g < 4) pr = i < 12 ? i * 4 + l : 48 + (i - 12) * 16 + l;
+                else pr = 48 + (g - 4) * 16 + 4 + i;
+                sPairF[pr] = tot;
+            }
         }
     }
-    {
-        const bool up = (lane & 16) != 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const double keep = up ? b8[i + 4] : b8[i], send = up ? b8[i] : b8[i + 4];
-            b4[i] = keep + __shfl_xor(send, 16, 64);
-        }
-    }
-    {
-        const bool up = (lane & 8) != 0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const double keep = up ? b4[i + 2] : b4[i], send = up ? b4[i] : b4[i + 2];
-            b2[i] = keep + __shfl_xor(send, 8, 64);
-        }
-    }
-    double v;
-    {
-        const bool up = (lane & 4) != 0;
-        const double keep = up ? b2[1] : b2[0], send = up ? b2[0] : b2[1];
-        v = keep + __shfl_xor(send, 4, 64);
-    }
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 1, 64);
-    return v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -367,14 +321,33 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
     const int lane = threadIdx.x;
     const int W = p.W, H = p.H, S = p.S, b = p.b;
 
-    // XCD-aware pixel assignment: blocks with equal (blockIdx % 8) share an XCD (and its L2); give each
-    // XCD one contiguous band of the slab so concurrently resident pixels share window data in L2.
-    const int64_t P = (int64_t)(p.row_end - p.row_begin) * W;
-    const int64_t band = (P + 7) / 8;
-    const int64_t q = (int64_t)(blockIdx.x & 7) * band + (blockIdx.x >> 3);
-    if ((int64_t)(blockIdx.x >> 3) >= band || q >= P) return;
-    const int y = p.row_begin + (int)(q / W);
-    const int x = (int)(q % W);
+    // XCD- and L2-aware pixel assignment.  Blocks with equal (blockIdx % 8) share an XCD and its 4 MiB L2:
+    // XCD r filters one contiguous band of rows, and walks it in vertical strips of kStripW pixels (row by row
+    // inside a strip), so the 7-row window data of the ~256 pixels in flight on the XCD (and the 6 rows shared
+    // with the next strip row) stay L2-resident instead of being re-fetched once per image row.
+    constexpr int kStripW = 128;
+    const int rows_own = p.row_end - p.row_begin;
+    const int rows_band = (rows_own + 7) / 8;
+    const int band_row0 = (int)(blockIdx.x & 7) * rows_band;
+    const int band_rows = min(rows_band, rows_own - band_row0);
+    if (band_rows <= 0) return;
+    const int64_t ql = (int64_t)(blockIdx.x >> 3);
+    if (ql >= (int64_t)band_rows * W) return;
+    const int full_strips = W / kStripW;
+    const int64_t strip_px = (int64_t)kStripW * band_rows;
+    int x, yl;
+    if (ql < full_strips * strip_px) {
+        const int sidx = (int)(ql / strip_px);
+        const int r = (int)(ql - sidx * strip_px);
+        yl = r / kStripW;
+        x = sidx * kStripW + (r - yl * kStripW);
+    } else {
+        const int tw = W - full_strips * kStripW;
+        const int r = (int)(ql - full_strips * strip_px);
+        yl = r / tw;
+        x = full_strips * kStripW + (r - yl * tw);
+    }
+    const int y = p.row_begin + band_row0 + yl;
     const uint64_t HW = (uint64_t)H * W;
     const uint64_t pix = (uint64_t)y * W + x;
 
@@ -401,30 +374,42 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             m12[k] = p.pmean[(uint64_t)k * HW + pix];
             lim12[k] = p.pstd[(uint64_t)k * HW + pix] * 3.0; // multiplyArray(std, 3), rpf.cpp:579
         }
+        // candidate -> plane offset of its sample, in the reference's visiting order
+        auto cand_off = [&](int qq) -> uint32_t {
+            int cell = qq / S;
+            const int s = qq - cell * S;
+            if (cell >= centre_rank) ++cell;          // rpf.cpp:565: skip the centre pixel
+            const int ix = cell / nyv;                 // xn outer ascending (rpf.cpp:562)
+            const int iy = cell - ix * nyv;            // yn inner ascending (rpf.cpp:563)
+            return (uint32_t)(((uint64_t)(y0 + iy) * W + (x0 + ix)) * S + s);
+        };
+        // the 12 feature gathers of chunk q0+64 are in flight while chunk q0 is tested and appended
+        float f[kNFeat], fn[kNFeat];
+        uint32_t off = 0, offn = 0;
+        if (lane < ncand) {
+            off = cand_off(lane);
+#pragma unroll
+            for (int k = 0; k < kNFeat; ++k) f[k] = p.planes[(uint64_t)(kColF + k) * p.plane_stride + off];
+        }
         for (int q0 = 0; q0 < ncand; q0 += kWave) {
-            const int qq = q0 + lane;
-            bool pass = false;
-            uint32_t off = 0;
-            if (qq < ncand) {
-                int cell = qq / S;
-                const int s = qq - cell * S;
-                if (cell >= centre_rank) ++cell;          // rpf.cpp:565: skip the centre pixel
-                const int ix = cell / nyv;                 // xn outer ascending (rpf.cpp:562)
-                const int iy = cell - ix * nyv;            // yn inner ascending (rpf.cpp:563)
-                off = (uint32_t)(((uint64_t)(y0 + iy) * W + (x0 + ix)) * S + s);
-                float f[kNFeat];
+            const int qn = q0 + kWave + lane;
+            if (qn < ncand) {
+                offn = cand_off(qn);
 #pragma unroll
-                for (int k = 0; k < kNFeat; ++k) f[k] = p.planes[(uint64_t)(kColF + k) * p.plane_stride + off];
-                pass = true;
+                for (int k = 0; k < kNFeat; ++k) fn[k] = p.planes[(uint64_t)(kColF + k) * p.plane_stride + offn];
+            }
+            bool pass = (q0 + lane) < ncand;
 #pragma unroll
-                for (int k = 0; k < kNFeat; ++k) {
-                    const double a = fabs((double)f[k] - m12[k]);
-                    if (a >= lim12[k]) pass = false;       // allLessThan: fails iff a >= b (ops.h:101-104)
-                }
+            for (int k = 0; k < kNFeat; ++k) {
+                const double a = fabs((double)f[k] - m12[k]);
+                if (a >= lim12[k]) pass = false;           // allLessThan: fails iff a >= b (ops.h:101-104)
             }
             const unsigned long long mask = __ballot(pass);
             if (pass) sOff[n + __popcll(mask & ((1ull << lane) - 1ull))] = off;
             n += __popcll(mask);
+            off = offn;
+#pragma unroll
+            for (int k = 0; k < kNFeat; ++k) f[k] = fn[k];
         }
     }
     wsync();
@@ -535,8 +520,8 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             float a32[32];
 #pragma unroll
             for (int i = 0; i < 16; ++i) { a32[i] = fmn[i]; a32[16 + i] = -fmx[i]; }
-            const float r = reduce32_min(a32, lane);
-            const int slot = reduce32_slot(lane);
+            const float r = xl::reduce32<xl::OpMin>(a32, lane);
+            const int slot = xl::slot32(lane);
             if ((lane & 1) == 0) {
                 const int i = slot & 15;
                 const int col = i < 2 ? i : i + 3;
@@ -545,7 +530,7 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const double lo = wave_min(cmn[i]), hi = wave_max(cmx[i]);
+                const double lo = xl::allreduce<xl::OpMin>(cmn[i]), hi = xl::allreduce<xl::OpMax>(cmx[i]);
                 if (lane == 0) { sStat[2 * kNDim + kColC + i] = lo; sStat[3 * kNDim + kColC + i] = hi; }
             }
         }
@@ -561,8 +546,23 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
         uint32_t offk[K];
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) offk[kk] = (lane + kWave * kk < n) ? sOff[lane + kWave * kk] : 0u;
+        auto load_column = [&](int c, double (&dst)[K]) {
+            if (c >= kColC && c < kColC + 3) {
+                const double *dplane = p.col_in + (uint64_t)(c - kColC) * p.plane_stride;
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) dst[kk] = dplane[offk[kk]];
+            } else {
+                const float *fplane = p.planes + (uint64_t)c * p.plane_stride;
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) dst[kk] = (double)fplane[offk[kk]];
+            }
+        };
+        const int ncol = (p.stage_mask & 2) ? kNDim : 0;
+        double xv[K], xnext[K];
+        if (ncol) load_column(0, xv);
 #pragma unroll 1
-        for (int c = 0; c < ((p.stage_mask & 2) ? kNDim : 0); ++c) {
+        for (int c = 0; c < ncol; ++c) {
+            if (c + 1 < ncol) load_column(c + 1, xnext); // next column's gathers fly during this column's quotients
             const double Mc = sStat[c], SDc = sStat[kNDim + c];
             const double xlo = sStat[2 * kNDim + c], xhi = sStat[3 * kNDim + c];
             const bool sd0 = (SDc == 0.0);
@@ -573,35 +573,42 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             const bool flat = !(hi != lo);                       // mi.cpp:7 / 28 / 34
             const UDiv drg = udiv_prepare(range);
             const bool fast = dsd.fast && (flat || drg.fast);   // wave-uniform
-            const bool is_colour = (c >= kColC && c < kColC + 3);
-            const float *fplane = p.planes + (uint64_t)c * p.plane_stride;
-            const double *dplane = p.col_in + (uint64_t)(is_colour ? c - kColC : 0) * p.plane_stride;
             uint32_t w[KW];
 #pragma unroll
             for (int q4 = 0; q4 < KW; ++q4) w[q4] = 0u;
-            double xv[K];
-            if (is_colour) {
+            if (fast && !sd0 && !flat) {
+                // the common case, straight-line for all K samples of the lane (holes compute on a dummy value
+                // and are masked at the pack), so the K dependent chains interleave
 #pragma unroll
-                for (int kk = 0; kk < K; ++kk) xv[kk] = (kk < (n + kWave - 1) / kWave) ? dplane[offk[kk]] : 0.0;
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < K; ++kk) xv[kk] = (kk < (n + kWave - 1) / kWave) ? (double)fplane[offk[kk]] : 0.0;
-            }
-#pragma unroll
-            for (int kk = 0; kk < K; ++kk) {
-                if (lane + kWave * kk < n) {
-                    const double a = xv[kk] - Mc;                                              // subtractArrays
-                    const double z = sd0 ? 0.0 : (fast ? udiv_fast(a, dsd) : a / SDc);         // divideArrays, ops.h:48
-                    int bin = 0;
-                    if (!flat) {
-                        const double t = (fast ? udiv_fast(z - lo, drg) : (z - lo) / range) * dB; // mi.cpp:14
-                        bin = (int)t;
-                        bin = min(bin, B - 1);
-                        bin = max(bin, 0);
-                    }
+                for (int kk = 0; kk < K; ++kk) {
+                    const double a = xv[kk] - Mc;                          // subtractArrays
+                    const double z = udiv_fast(a, dsd);                    // divideArrays, ops.h:48
+                    const double t = udiv_fast(z - lo, drg) * dB;          // mi.cpp:14
+                    int bin = (int)t;
+                    bin = min(bin, B - 1);
+                    bin = max(bin, 0);
+                    bin = (lane + kWave * kk < n) ? bin : 0;
                     w[kk >> 2] |= (uint32_t)bin << (8 * (kk & 3));
                 }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) {
+                    if (lane + kWave * kk < n) {
+                        const double a = xv[kk] - Mc;
+                        const double z = sd0 ? 0.0 : a / SDc;
+                        int bin = 0;
+                        if (!flat) {
+                            const double t = (z - lo) / range * dB;
+                            bin = (int)t;
+                            bin = min(bin, B - 1);
+                            bin = max(bin, 0);
+                        }
+                        w[kk >> 2] |= (uint32_t)bin << (8 * (kk & 3));
+                    }
+                }
             }
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) xv[kk] = xnext[kk];
             store_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, w);
         }
     }
@@ -612,109 +619,25 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
         for (int j = 0; j < n; ++j) h = fnv1a_u16(h, bytes[(j & 63) * (KW * 4) + (j >> 6)]);
         p.dbg.bin_hash[pix * kNDim + lane] = h;
     }
-    // ---------------- stage 3b: histograms -> mutual information (mi.cpp:45-90) -----------------
-    // mi.cpp:79-86 over integer counts:  N*MI = T[N] + sum_ij T[J_ij] - sum_i T[hx_i] - sum_j T[hy_j],
-    // T[k] = k ln k.  T is tabulated in 2^-44 fixed point, so every sum below is an exact integer sum:
-    // the result does not depend on the order in which lanes hit a cell, a single-bin column gives exactly
-    // MI == 0 like the reference (pX == 1 => every log term is log(1)), and no log is evaluated here.
-    // Each increment is a returning LDS atomic; the old count c contributes D[c] = T[c+1]-T[c], which
-    // telescopes to T[J] per cell.  The histogram is cleared by wide stores issued right behind the
-    // atomics (one wave's LDS operations execute in order); the D look-ups of a histogram are issued after
-    // the atomics of the NEXT one, so the LDS pipe always has independent work queued.
-    const int ncell2 = B * B;
-    zero_words(sHist, ncell2, lane);
-    const int kdyn = (n + kWave - 1) / kWave;         // wave-uniform: sample slots kk < kdyn exist
-    uint32_t inc[K];                                  // 1 for an existing sample, 0 for a hole in the last slot
-#pragma unroll
-    for (int kk = 0; kk < K; ++kk) inc[kk] = (lane + kWave * kk < n) ? 1u : 0u;
-    const uint32_t hole1 = (uint32_t)min(lane, B - 1);      // harmless targets of the +0 atomics of holes
-    const uint32_t hole2 = (uint32_t)min(lane, ncell2 - 1);
-
-    auto col_words = [&](int c, uint32_t (&w)[KW]) { load_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, w); };
-    // issue the K returning atomics of one histogram, then the clearing stores behind them
-    auto issue = [&](const uint32_t (&key)[K], uint32_t (&old)[K], int cells) {
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk)
-            if (kk < kdyn) old[kk] = atomicAdd(&sHist[key[kk]], inc[kk]);
-        zero_words(sHist, cells, lane);
-    };
-    auto consume = [&](const uint32_t (&old)[K]) -> uint64_t {
-        uint64_t d[K];
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk) d[kk] = (kk < kdyn) ? Dl(old[kk]) : 0ull;
-        uint64_t a = 0ull;
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk) a += inc[kk] ? d[kk] : 0ull;
-        return a;
-    };
-
+    // ---------------- stage 3b: histograms -> mutual information: mi_stage() above ------------
 #ifndef RPF_X_SKIPMI
     if (p.stage_mask & 4) {
-        // Histograms are processed four at a time (runtime loop over groups, so the code stays small): within a
-        // group the atomics of histogram u+1 are queued before the look-ups of histogram u are consumed, and
-        // the four per-lane sums are reduced together by one transposed butterfly (7 exchanges).
-        // marginals: sum_i T[hx_i] per column
-#pragma unroll 1
-        for (int c0 = 0; c0 < kNDim; c0 += 4) {
-            uint64_t acc4[4] = {0ull, 0ull, 0ull, 0ull};
-            uint32_t oldA[K], oldB[K];
-#pragma unroll
-            for (int u = 0; u <= 4; ++u) {
-                if (u < 4 && c0 + u < kNDim) { // wave-uniform
-                    uint32_t w[KW], key[K];
-                    col_words(c0 + u, w);
-#pragma unroll
-                    for (int kk = 0; kk < K; ++kk)
-                        key[kk] = inc[kk] ? ((w[kk >> 2] >> (8 * (kk & 3))) & 0xffu) : hole1;
-                    if (u & 1) issue(key, oldB, B); else issue(key, oldA, B);
-                }
-                if (u >= 1 && c0 + u - 1 < kNDim) acc4[u - 1] = consume(((u - 1) & 1) ? oldB : oldA);
+        const uint64_t *dtab = T_IN_LDS ? sD : p.dfix;
+        const int kdyn = (n + kWave - 1) / kWave; // wave-uniform: sample slots kk < kdyn exist
+        if constexpr (K <= 8) {
+            // one straight-line instantiation per number of occupied sample slots: no branch sits between the
+            // LDS operations of a histogram group, so they pipeline under counted lgkmcnt waits
+            switch (kdyn) {
+            case 1: mi_stage<1, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); break;
+            case 2: if constexpr (K >= 2) mi_stage<2, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); break;
+            case 3: if constexpr (K >= 3) mi_stage<3, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); break;
+            case 4: if constexpr (K >= 4) mi_stage<4, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); break;
+            case 5: if constexpr (K >= 5) mi_stage<5, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); break;
+            case 6: if constexpr (K >= 6) mi_stage<6, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); break;
+            default: if constexpr (K >= 7) mi_stage<K, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); break;
             }
-            const uint64_t tot = reduce4(acc4, lane);
-            const int c = c0 + reduce4_slot(lane);
-            if ((lane & 15) == 0 && c < kNDim) sHXf[c] = tot;
-        }
-        // joint histograms, grouped by an anchor column whose (bin * B) stays in registers
-        //   anchors 0..3 = r0, r1, p0, p1 with partners f0..f11, c0..c2 ; anchors 4..6 = c0..c2 with f0..f11
-#pragma unroll 1
-        for (int g = 0; g < 7; ++g) {
-            const int np = g < 4 ? 15 : 12;
-            const int acol = g < 2 ? kColR + g : (g < 4 ? kColP + (g - 2) : kColC + (g - 4));
-            const int l = g < 2 ? g : 2 + (g - 2); // r0,r1 -> 0,1 ; p0,p1 -> 2,3
-            uint32_t akey[K];
-            {
-                uint32_t w[KW];
-                col_words(acol, w);
-#pragma unroll
-                for (int kk = 0; kk < K; ++kk) akey[kk] = ((w[kk >> 2] >> (8 * (kk & 3))) & 0xffu) * (uint32_t)B;
-            }
-#pragma unroll 1
-            for (int i0 = 0; i0 < np; i0 += 4) {
-                uint64_t acc4[4] = {0ull, 0ull, 0ull, 0ull};
-                uint32_t oldA[K], oldB[K];
-#pragma unroll
-                for (int u = 0; u <= 4; ++u) {
-                    if (u < 4 && i0 + u < np) { // wave-uniform
-                        const int i = i0 + u;
-                        uint32_t w[KW], key[K];
-                        col_words(i < 12 ? kColF + i : kColC + (i - 12), w);
-#pragma unroll
-                        for (int kk = 0; kk < K; ++kk)
-                            key[kk] = inc[kk] ? akey[kk] + ((w[kk >> 2] >> (8 * (kk & 3))) & 0xffu) : hole2; // mi.cpp:39
-                        if (u & 1) issue(key, oldB, ncell2); else issue(key, oldA, ncell2);
-                    }
-                    if (u >= 1 && i0 + u - 1 < np) acc4[u - 1] = consume(((u - 1) & 1) ? oldB : oldA);
-                }
-                const uint64_t tot = reduce4(acc4, lane);
-                const int i = i0 + reduce4_slot(lane);
-                if ((lane & 15) == 0 && i < np) {
-                    // pair index in ComputeCFWeights call order (rpf.cpp:416-442)
-                    int pr;
-                    if (g < 4) pr = i < 12 ? i * 4 + l : 48 + (i - 12) * 16 + l;
-                    else pr = 48 + (g - 4) * 16 + 4 + i;
-                    sPairF[pr] = tot;
-                }
-            }
+        } else {
+            mi_stage<K, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);
         }
     }
 #endif
@@ -816,14 +739,30 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
         double sw[8], s0[8], s1[8], s2[8];
 #pragma unroll
         for (int ii = 0; ii < 8; ++ii) { sw[ii] = 0.0; s0[ii] = 0.0; s1[ii] = 0.0; s2[ii] = 0.0; }
+        // raw values of the lane's next neighbourhood sample are gathered while the current one is weighted
+        float pf[14];  // columns 0,1 (pFilm) and 7..18 (features)
+        double pc[3];  // colours
+        auto fetch17 = [&](int j) {
+            if (j < n) {
+                const uint32_t off = sOff[j];
+#pragma unroll
+                for (int k = 0; k < 14; ++k) pf[k] = p.planes[(uint64_t)(k < 2 ? k : k + 5) * p.plane_stride + off];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) pc[k] = p.col_in[(uint64_t)k * p.plane_stride + off];
+            }
+        };
+        fetch17(lane);
 #pragma unroll 1
         for (int kk = 0; kk < K; ++kk) {
             const int j = lane + kWave * kk;
             if (j >= n) break;
-            const uint32_t off = sOff[j];
-            double xj[17];
+            double xj[17]; // order: p0 p1 | c0 c1 c2 | f0..f11
+            xj[0] = (double)pf[0]; xj[1] = (double)pf[1];
 #pragma unroll
-            for (int k = 0; k < 17; ++k) xj[k] = load_col(p, k < 5 ? k : k + 2, off);
+            for (int k = 0; k < 3; ++k) xj[2 + k] = pc[k];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) xj[5 + k] = (double)pf[2 + k];
+            fetch17(j + kWave);
 #pragma unroll
             for (int ii = 0; ii < 8; ++ii) {
                 const int i = i0 + ii;
@@ -848,11 +787,11 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             double ga[16], gb[16];
 #pragma unroll
             for (int ii = 0; ii < 8; ++ii) { ga[ii] = sw[ii]; ga[8 + ii] = s0[ii]; gb[ii] = s1[ii]; gb[8 + ii] = s2[ii]; }
-            const double ta = reduce16_sum(ga, lane), tb = reduce16_sum(gb, lane);
+            const double ta = xl::reduce16<xl::OpSum>(ga, lane), tb = xl::reduce16<xl::OpSum>(gb, lane);
             wsync();
             if ((lane & 3) == 0) {
-                sMI[reduce16_slot(lane)] = ta;
-                sMI[16 + reduce16_slot(lane)] = tb;
+                sMI[xl::slot16(lane)] = ta;
+                sMI[16 + xl::slot16(lane)] = tb;
             }
             wsync();
             if (lane < 24) {
@@ -985,7 +924,11 @@ int samples_per_lane(int nmax) {
     return 0;
 }
 
-bool table_in_lds(int nmax) { return (uint32_t)nmax * 8u <= 8192u; }
+bool table_in_lds(int nmax) {
+    const char *e = std::getenv("RPF_TABLE_IN_LDS"); // experiment knob
+    if (e) return std::atoi(e) != 0 && (uint32_t)nmax * 8u <= 65536u;
+    return (uint32_t)nmax * 8u <= 8192u;
+}
 
 LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     LdsLayout L{};
@@ -1028,9 +971,9 @@ hipError_t launch_filter_pass(const PassParams &p, hipStream_t s, uint32_t *lds_
     const LdsLayout L = lds_layout(p.S, p.nmax, p.bmax, t_in_lds);
     if (lds_bytes_out) *lds_bytes_out = L.total;
     if ((int)L.total > max_lds_per_block()) return hipErrorInvalidValue;
-    const int64_t P = (int64_t)(p.row_end - p.row_begin) * p.W;
-    if (P <= 0) return hipSuccess;
-    const int64_t band = (P + 7) / 8;
+    const int rows_own = p.row_end - p.row_begin;
+    if (rows_own <= 0) return hipSuccess;
+    const int64_t band = (int64_t)((rows_own + 7) / 8) * p.W; // pixels per XCD band (see the kernel's mapping)
     const unsigned grid = (unsigned)(band * 8);
     switch (samples_per_lane(p.nmax)) {
     case 1: return launch_filter_k<1>(p, L, t_in_lds, grid, s);
