@@ -188,14 +188,19 @@ __device__ __forceinline__ double udiv(double a, const UDiv &d) {
 // operations execute in order).  Histograms are processed four at a time: the atomics of histogram u+1 are
 // queued before the D look-ups of histogram u are consumed, and the four per-lane sums are reduced together by
 // one transposed butterfly (no LDS).  KD = number of occupied sample slots of this pixel (compile time).
+// ZN > 0: the buffer holds >= 256*ZN cells and ZN unconditional full-wave 16-byte stores clear it (no exec
+// masking, no branch: cells past the live histogram are scratch).  ZN == 0: generic loop (large neighbourhoods).
+template <int ZN>
 __device__ __forceinline__ void zero_cells(uint32_t *h, int cells, int lane) {
-    // cells <= 512 in the common (K <= 8) case: two predicated 16-byte stores, no loop
-    if (lane * 4 < cells) *reinterpret_cast<uint4 *>(h + lane * 4) = make_uint4(0u, 0u, 0u, 0u);
-    if (lane * 4 + 256 < cells) *reinterpret_cast<uint4 *>(h + lane * 4 + 256) = make_uint4(0u, 0u, 0u, 0u);
-    for (int t = lane * 4 + 512; t < cells; t += kWave * 4) *reinterpret_cast<uint4 *>(h + t) = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (ZN > 0) {
+#pragma unroll
+        for (int i = 0; i < ZN; ++i) *reinterpret_cast<uint4 *>(h + lane * 4 + 256 * i) = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        for (int t = lane * 4; t < cells; t += kWave * 4) *reinterpret_cast<uint4 *>(h + t) = make_uint4(0u, 0u, 0u, 0u);
+    }
 }
 
-template <int KD, int KW>
+template <int KD, int KW, int ZN>
 __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, uint64_t *sHXf,
                                          uint64_t *sPairF, int lane, int n, int B) {
     const int ncell2 = B * B;
@@ -204,7 +209,7 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
     for (int kk = 0; kk < KD; ++kk) inc[kk] = (lane + kWave * kk < n) ? 1u : 0u;
     const uint32_t hole1 = (uint32_t)min(lane, B - 1);      // harmless, spread-out targets of the +0 atomics
     const uint32_t hole2 = (uint32_t)min(lane, ncell2 - 1);
-    zero_cells(sHist, ncell2, lane);
+    zero_cells<ZN>(sHist, ncell2, lane);
 
     auto byte_of = [](const uint32_t (&w)[KW], int kk) -> uint32_t { return (w[kk >> 2] >> (8 * (kk & 3))) & 0xffu; };
 
@@ -225,7 +230,7 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
                     const bool on = live && inc[kk];
                     old[u & 1][kk] = atomicAdd(&sHist[on ? byte_of(w, kk) : hole1], on ? 1u : 0u);
                 }
-                zero_cells(sHist, B, lane);
+                zero_cells<(ZN > 0 ? 1 : 0)>(sHist, B, lane);
             }
             if (u >= 1) {
                 const bool live = (c0 + u - 1) < kNDim;
@@ -272,7 +277,7 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
                         const bool on = live && inc[kk];
                         old[u & 1][kk] = atomicAdd(&sHist[on ? akey[kk] + byte_of(w, kk) : hole2], on ? 1u : 0u); // mi.cpp:39
                     }
-                    zero_cells(sHist, ncell2, lane);
+                    zero_cells<ZN>(sHist, ncell2, lane);
                 }
                 if (u >= 1) {
                     const bool live = (i0 + u - 1) < np;
@@ -625,19 +630,27 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
         const uint64_t *dtab = T_IN_LDS ? sD : p.dfix;
         const int kdyn = (n + kWave - 1) / kWave; // wave-uniform: sample slots kk < kdyn exist
         if constexpr (K <= 8) {
-            // one straight-line instantiation per number of occupied sample slots: no branch sits between the
-            // LDS operations of a histogram group, so they pipeline under counted lgkmcnt waits
+            // one straight-line instantiation per number of occupied sample slots (and per number of 1-KiB clearing
+            // stores): no branch sits between the LDS operations of a histogram group, so they pipeline under
+            // counted lgkmcnt waits
+#define RPF_MI_CASE(KD_)                                                                                     \
+    if constexpr (K >= KD_) {                                                                                \
+        if (B * B > 256) mi_stage<KD_, KW, 2>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);                 \
+        else mi_stage<KD_, KW, 1>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);                             \
+    }
             switch (kdyn) {
-            case 1: mi_stage<1, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); break;
-            case 2: if constexpr (K >= 2) mi_stage<2, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); break;
-            case 3: if constexpr (K >= 3) mi_stage<3, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); break;
-            case 4: if constexpr (K >= 4) mi_stage<4, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); break;
-            case 5: if constexpr (K >= 5) mi_stage<5, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); break;
-            case 6: if constexpr (K >= 6) mi_stage<6, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); break;
-            default: if constexpr (K >= 7) mi_stage<K, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); break;
+            case 1: RPF_MI_CASE(1) break;
+            case 2: RPF_MI_CASE(2) break;
+            case 3: RPF_MI_CASE(3) break;
+            case 4: RPF_MI_CASE(4) break;
+            case 5: RPF_MI_CASE(5) break;
+            case 6: RPF_MI_CASE(6) break;
+            case 7: RPF_MI_CASE(7) break;
+            default: RPF_MI_CASE(8) break;
             }
+#undef RPF_MI_CASE
         } else {
-            mi_stage<K, KW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);
+            mi_stage<K, KW, 0>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);
         }
     }
 #endif
@@ -948,7 +961,9 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     const uint32_t bins = align_up((uint32_t)kNDim * kWave * KW * 4u, 16);
     o += bins > stage ? bins : stage;
     L.off_hist = o;
-    o += align_up((uint32_t)bmax * (uint32_t)bmax * 4u, 16);
+    uint32_t cells = (uint32_t)bmax * (uint32_t)bmax;
+    if (K <= 8 && cells < 512u) cells = 512u; // mi_stage clears with unconditional 1-KiB stores
+    o += align_up(cells * 4u, 16);
     L.total = o;
     return L;
 }
