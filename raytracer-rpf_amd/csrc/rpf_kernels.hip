@@ -54,8 +54,14 @@ constexpr PairTable make_pairs() {
 }
 __constant__ PairTable c_pairs = make_pairs();
 
-// the workgroup is exactly one wavefront: the barrier is an LDS/memory ordering point, not a rendezvous
-__device__ __forceinline__ void wsync() { __syncthreads(); }
+// The workgroup is exactly one wavefront, and one wave's LDS operations execute in issue order, so a
+// producer/consumer hand-off between lanes through LDS needs no s_barrier and no counter drain (a
+// __syncthreads() here would also wait for every gather in flight: vmcnt(0)).  What it needs is that the
+// compiler keeps the program order of the memory operations: a wavefront-scope fence.
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ uint32_t fnv1a_u32(uint32_t h, uint32_t v) {
 #pragma unroll
@@ -200,105 +206,106 @@ __device__ __forceinline__ void zero_cells(uint32_t *h, int cells, int lane) {
     }
 }
 
-template <int KD, int KW, int ZN>
+// One group of G (3 or 4) histograms, straight-line.  For marginals (JOINT = false) histogram u bins column
+// col0+u; for joints it bins (anchor, partner col(u)).  Slots kk < KD-1 are full by definition of KD (= ceil(n/64)),
+// so only the last slot carries the hole mask: `lastkey_ok` lanes exist, the others aim a +0 atomic at `hole`.
+// FULL = false (large neighbourhoods, KD = K): every slot carries its own mask (lane + 64*kk < n).
+template <int KD, int KW, int ZN, int G, bool JOINT, bool FULL>
+__device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, int lane, int n,
+                                         const int (&cols)[4], const uint32_t (&akey)[KD], bool last_ok, uint32_t hole,
+                                         int cells, uint64_t (&acc4)[4]) {
+    uint32_t old[2][KD];
+    const uint32_t one = 1u, last_inc = last_ok ? 1u : 0u;
+    auto slot_ok = [&](int kk) -> bool { return FULL ? (kk < KD - 1 ? true : last_ok) : (lane + kWave * kk < n); };
+#pragma unroll
+    for (int u = 0; u <= G; ++u) {
+        if (u < G) {
+            uint32_t w[KW];
+            load_words<KW>(sBinW + ((size_t)cols[u] * kWave + lane) * KW, w);
+#pragma unroll
+            for (int kk = 0; kk < KD; ++kk) {
+                uint32_t key = (w[kk >> 2] >> (8 * (kk & 3))) & 0xffu;
+                if (JOINT) key += akey[kk];                                  // mi.cpp:39
+                if (FULL) {
+                    if (kk == KD - 1) key = last_ok ? key : hole;
+                    old[u & 1][kk] = atomicAdd(&sHist[key], kk == KD - 1 ? last_inc : one);
+                } else {
+                    const bool ok = slot_ok(kk);
+                    old[u & 1][kk] = atomicAdd(&sHist[ok ? key : hole], ok ? 1u : 0u);
+                }
+            }
+            zero_cells<(JOINT ? ZN : (ZN > 0 ? 1 : 0))>(sHist, cells, lane);
+        }
+        if (u >= 1) {
+            uint64_t d[KD];
+#pragma unroll
+            for (int kk = 0; kk < KD; ++kk) d[kk] = dtab[old[(u - 1) & 1][kk]];
+            uint64_t a = slot_ok(KD - 1) ? d[KD - 1] : 0ull;
+#pragma unroll
+            for (int kk = 0; kk < KD - 1; ++kk) a += slot_ok(kk) ? d[kk] : 0ull;
+            acc4[u - 1] = a;
+        }
+    }
+#pragma unroll
+    for (int u = G; u < 4; ++u) acc4[u] = 0ull;
+}
+
+template <int KD, int KW, int ZN, bool FULL>
 __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, uint64_t *sHXf,
                                          uint64_t *sPairF, int lane, int n, int B) {
     const int ncell2 = B * B;
-    uint32_t inc[KD]; // 1 for an existing sample, 0 for a hole in the last slot
-#pragma unroll
-    for (int kk = 0; kk < KD; ++kk) inc[kk] = (lane + kWave * kk < n) ? 1u : 0u;
+    const bool last_ok = (lane + kWave * (KD - 1)) < n;     // does this lane's last sample slot exist?
     const uint32_t hole1 = (uint32_t)min(lane, B - 1);      // harmless, spread-out targets of the +0 atomics
     const uint32_t hole2 = (uint32_t)min(lane, ncell2 - 1);
     zero_cells<ZN>(sHist, ncell2, lane);
+    uint32_t akey[KD];
+#pragma unroll
+    for (int kk = 0; kk < KD; ++kk) akey[kk] = 0u;
 
-    auto byte_of = [](const uint32_t (&w)[KW], int kk) -> uint32_t { return (w[kk >> 2] >> (8 * (kk & 3))) & 0xffu; };
-
-    // ---- marginals: sum_i T[hx_i] per column, four columns per group (the 20th slot repeats column 18 with +0)
+    // ---- marginals: sum_i T[hx_i] per column; 19 columns = 4 groups of 4 + one group of 3
 #pragma unroll 1
-    for (int c0 = 0; c0 < kNDim; c0 += 4) {
+    for (int c0 = 0; c0 < 16; c0 += 4) {
         uint64_t acc4[4];
-        uint32_t old[2][KD];
-#pragma unroll
-        for (int u = 0; u <= 4; ++u) {
-            if (u < 4) {
-                const int c = min(c0 + u, kNDim - 1);
-                const bool live = (c0 + u) < kNDim;
-                uint32_t w[KW];
-                load_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, w);
-#pragma unroll
-                for (int kk = 0; kk < KD; ++kk) {
-                    const bool on = live && inc[kk];
-                    old[u & 1][kk] = atomicAdd(&sHist[on ? byte_of(w, kk) : hole1], on ? 1u : 0u);
-                }
-                zero_cells<(ZN > 0 ? 1 : 0)>(sHist, B, lane);
-            }
-            if (u >= 1) {
-                const bool live = (c0 + u - 1) < kNDim;
-                uint64_t d[KD];
-#pragma unroll
-                for (int kk = 0; kk < KD; ++kk) d[kk] = dtab[old[(u - 1) & 1][kk]];
-                uint64_t a = 0ull;
-#pragma unroll
-                for (int kk = 0; kk < KD; ++kk) a += (live && inc[kk]) ? d[kk] : 0ull;
-                acc4[u - 1] = a;
-            }
-        }
+        const int cols[4] = {c0, c0 + 1, c0 + 2, c0 + 3};
+        mi_group<KD, KW, ZN, 4, false, FULL>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole1, B, acc4);
         const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
-        const int c = c0 + xl::slot4(lane);
-        if ((lane & 15) == 0 && c < kNDim) sHXf[c] = tot;
+        if ((lane & 15) == 0) sHXf[c0 + xl::slot4(lane)] = tot;
+    }
+    {
+        uint64_t acc4[4];
+        const int cols[4] = {16, 17, 18, 18};
+        mi_group<KD, KW, ZN, 3, false, FULL>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole1, B, acc4);
+        const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
+        if ((lane & 15) == 0 && xl::slot4(lane) < 3) sHXf[16 + xl::slot4(lane)] = tot;
     }
     // ---- joint histograms, grouped by an anchor column whose (bin * B) stays in registers
     //   anchors 0..3 = r0, r1, p0, p1 with partners f0..f11, c0..c2 ; anchors 4..6 = c0..c2 with f0..f11
 #pragma unroll 1
     for (int g = 0; g < 7; ++g) {
-        const int np = g < 4 ? 15 : 12;
         const int acol = g < 2 ? kColR + g : (g < 4 ? kColP + (g - 2) : kColC + (g - 4));
         const int l = g < 2 ? g : 2 + (g - 2); // r0,r1 -> 0,1 ; p0,p1 -> 2,3
-        uint32_t akey[KD];
         {
             uint32_t w[KW];
             load_words<KW>(sBinW + ((size_t)acol * kWave + lane) * KW, w);
 #pragma unroll
-            for (int kk = 0; kk < KD; ++kk) akey[kk] = byte_of(w, kk) * (uint32_t)B;
+            for (int kk = 0; kk < KD; ++kk) akey[kk] = ((w[kk >> 2] >> (8 * (kk & 3))) & 0xffu) * (uint32_t)B;
         }
+        // pair index in ComputeCFWeights call order (rpf.cpp:416-442)
+        auto pair_index = [&](int i) { return g < 4 ? (i < 12 ? i * 4 + l : 48 + (i - 12) * 16 + l) : 48 + (g - 4) * 16 + 4 + i; };
 #pragma unroll 1
-        for (int i0 = 0; i0 < np; i0 += 4) {
+        for (int i0 = 0; i0 < 12; i0 += 4) { // partners f0..f11
             uint64_t acc4[4];
-            uint32_t old[2][KD];
-#pragma unroll
-            for (int u = 0; u <= 4; ++u) {
-                if (u < 4) {
-                    const int i = min(i0 + u, np - 1);
-                    const bool live = (i0 + u) < np;
-                    uint32_t w[KW];
-                    load_words<KW>(sBinW + ((size_t)(i < 12 ? kColF + i : kColC + (i - 12)) * kWave + lane) * KW, w);
-#pragma unroll
-                    for (int kk = 0; kk < KD; ++kk) {
-                        const bool on = live && inc[kk];
-                        old[u & 1][kk] = atomicAdd(&sHist[on ? akey[kk] + byte_of(w, kk) : hole2], on ? 1u : 0u); // mi.cpp:39
-                    }
-                    zero_cells<ZN>(sHist, ncell2, lane);
-                }
-                if (u >= 1) {
-                    const bool live = (i0 + u - 1) < np;
-                    uint64_t d[KD];
-#pragma unroll
-                    for (int kk = 0; kk < KD; ++kk) d[kk] = dtab[old[(u - 1) & 1][kk]];
-                    uint64_t a = 0ull;
-#pragma unroll
-                    for (int kk = 0; kk < KD; ++kk) a += (live && inc[kk]) ? d[kk] : 0ull;
-                    acc4[u - 1] = a;
-                }
-            }
+            const int cols[4] = {kColF + i0, kColF + i0 + 1, kColF + i0 + 2, kColF + i0 + 3};
+            mi_group<KD, KW, ZN, 4, true, FULL>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole2, ncell2, acc4);
             const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
-            const int i = i0 + xl::slot4(lane);
-            if ((lane & 15) == 0 && i < np) {
-                // pair index in ComputeCFWeights call order (rpf.cpp:416-442)
-                int pr;
-                if (g < 4) pr = i < 12 ? i * 4 + l : 48 + (i - 12) * 16 + l;
-                else pr = 48 + (g - 4) * 16 + 4 + i;
-                sPairF[pr] = tot;
-            }
+            if ((lane & 15) == 0) sPairF[pair_index(i0 + xl::slot4(lane))] = tot;
+        }
+        if (g < 4) { // partners c0..c2 (wave-uniform branch)
+            uint64_t acc4[4];
+            const int cols[4] = {kColC, kColC + 1, kColC + 2, kColC + 2};
+            mi_group<KD, KW, ZN, 3, true, FULL>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole2, ncell2, acc4);
+            const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
+            if ((lane & 15) == 0 && xl::slot4(lane) < 3) sPairF[pair_index(12 + xl::slot4(lane))] = tot;
         }
     }
 }
@@ -388,33 +395,38 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             const int iy = cell - ix * nyv;            // yn inner ascending (rpf.cpp:563)
             return (uint32_t)(((uint64_t)(y0 + iy) * W + (x0 + ix)) * S + s);
         };
-        // the 12 feature gathers of chunk q0+64 are in flight while chunk q0 is tested and appended
-        float f[kNFeat], fn[kNFeat];
-        uint32_t off = 0, offn = 0;
-        if (lane < ncand) {
-            off = cand_off(lane);
+        // rotating register buffers: the 12 feature gathers of the next kPF1 64-candidate steps are in flight while
+        // a step is tested and appended (an L2/MALL round trip is ~1-2k cycles under load, a step ~0.5k)
+        constexpr int kPF1 = 3;
+        float fb[kPF1][kNFeat];
+        uint32_t ob[kPF1];
+        auto issue1 = [&](int qq, float (&f)[kNFeat], uint32_t &off) {
+            if (qq < ncand) {
+                off = cand_off(qq);
 #pragma unroll
-            for (int k = 0; k < kNFeat; ++k) f[k] = p.planes[(uint64_t)(kColF + k) * p.plane_stride + off];
-        }
-        for (int q0 = 0; q0 < ncand; q0 += kWave) {
-            const int qn = q0 + kWave + lane;
-            if (qn < ncand) {
-                offn = cand_off(qn);
-#pragma unroll
-                for (int k = 0; k < kNFeat; ++k) fn[k] = p.planes[(uint64_t)(kColF + k) * p.plane_stride + offn];
+                for (int k = 0; k < kNFeat; ++k) f[k] = p.planes[(uint64_t)(kColF + k) * p.plane_stride + off];
             }
-            bool pass = (q0 + lane) < ncand;
+        };
 #pragma unroll
-            for (int k = 0; k < kNFeat; ++k) {
-                const double a = fabs((double)f[k] - m12[k]);
-                if (a >= lim12[k]) pass = false;           // allLessThan: fails iff a >= b (ops.h:101-104)
+        for (int u = 0; u < kPF1; ++u) issue1(u * kWave + lane, fb[u], ob[u]);
+#pragma unroll 1
+        for (int q0 = 0; q0 < ncand; q0 += kWave * kPF1) {
+#pragma unroll
+            for (int u = 0; u < kPF1; ++u) {
+                const int qb = q0 + u * kWave;
+                if (qb < ncand) { // wave-uniform
+                    bool pass = (qb + lane) < ncand;
+#pragma unroll
+                    for (int k = 0; k < kNFeat; ++k) {
+                        const double a = fabs((double)fb[u][k] - m12[k]);
+                        if (a >= lim12[k]) pass = false;       // allLessThan: fails iff a >= b (ops.h:101-104)
+                    }
+                    const unsigned long long mask = __ballot(pass);
+                    if (pass) sOff[n + __popcll(mask & ((1ull << lane) - 1ull))] = ob[u];
+                    n += __popcll(mask);
+                    issue1(qb + kWave * kPF1 + lane, fb[u], ob[u]);
+                }
             }
-            const unsigned long long mask = __ballot(pass);
-            if (pass) sOff[n + __popcll(mask & ((1ull << lane) - 1ull))] = off;
-            n += __popcll(mask);
-            off = offn;
-#pragma unroll
-            for (int k = 0; k < kNFeat; ++k) f[k] = fn[k];
         }
     }
     wsync();
@@ -551,23 +563,8 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
         uint32_t offk[K];
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) offk[kk] = (lane + kWave * kk < n) ? sOff[lane + kWave * kk] : 0u;
-        auto load_column = [&](int c, double (&dst)[K]) {
-            if (c >= kColC && c < kColC + 3) {
-                const double *dplane = p.col_in + (uint64_t)(c - kColC) * p.plane_stride;
-#pragma unroll
-                for (int kk = 0; kk < K; ++kk) dst[kk] = dplane[offk[kk]];
-            } else {
-                const float *fplane = p.planes + (uint64_t)c * p.plane_stride;
-#pragma unroll
-                for (int kk = 0; kk < K; ++kk) dst[kk] = (double)fplane[offk[kk]];
-            }
-        };
-        const int ncol = (p.stage_mask & 2) ? kNDim : 0;
-        double xv[K], xnext[K];
-        if (ncol) load_column(0, xv);
-#pragma unroll 1
-        for (int c = 0; c < ncol; ++c) {
-            if (c + 1 < ncol) load_column(c + 1, xnext); // next column's gathers fly during this column's quotients
+        // one column: z, t, bin for the lane's K samples, packed into KW words
+        auto do_column = [&](int c, const double (&xv)[K]) {
             const double Mc = sStat[c], SDc = sStat[kNDim + c];
             const double xlo = sStat[2 * kNDim + c], xhi = sStat[3 * kNDim + c];
             const bool sd0 = (SDc == 0.0);
@@ -612,9 +609,41 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
                     }
                 }
             }
-#pragma unroll
-            for (int kk = 0; kk < K; ++kk) xv[kk] = xnext[kk];
             store_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, w);
+        };
+        if (p.stage_mask & 2) {
+            // the 16 fp32 columns (0,1,5..18) through kPF3 rotating register buffers, gathers kPF3 columns ahead
+            constexpr int kPF3 = 4;
+            float xb[kPF3][K];
+            auto colidx = [](int i) { return i < 2 ? i : i + 3; };
+            auto issue3 = [&](int i, float (&dst)[K]) {
+                const float *fplane = p.planes + (uint64_t)colidx(i) * p.plane_stride;
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) dst[kk] = fplane[offk[kk]];
+            };
+#pragma unroll
+            for (int u = 0; u < kPF3; ++u) issue3(u, xb[u]);
+#pragma unroll 1
+            for (int i0 = 0; i0 < 16; i0 += kPF3) {
+#pragma unroll
+                for (int u = 0; u < kPF3; ++u) {
+                    double xv[K];
+#pragma unroll
+                    for (int kk = 0; kk < K; ++kk) xv[kk] = (double)xb[u][kk];
+                    if (i0 + u + kPF3 < 16) issue3(i0 + u + kPF3, xb[u]);
+                    do_column(colidx(i0 + u), xv);
+                }
+            }
+            // the 3 fp64 colour columns
+            double xc[3][K];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double *dplane = p.col_in + (uint64_t)c * p.plane_stride;
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) xc[c][kk] = dplane[offk[kk]];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) do_column(kColC + c, xc[c]);
         }
     }
     wsync();
@@ -635,8 +664,8 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             // counted lgkmcnt waits
 #define RPF_MI_CASE(KD_)                                                                                     \
     if constexpr (K >= KD_) {                                                                                \
-        if (B * B > 256) mi_stage<KD_, KW, 2>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);                 \
-        else mi_stage<KD_, KW, 1>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);                             \
+        if (B * B > 256) mi_stage<KD_, KW, 2, true>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);                 \
+        else mi_stage<KD_, KW, 1, true>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);                             \
     }
             switch (kdyn) {
             case 1: RPF_MI_CASE(1) break;
@@ -650,7 +679,7 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             }
 #undef RPF_MI_CASE
         } else {
-            mi_stage<K, KW, 0>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);
+            mi_stage<K, KW, 0, false>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);
         }
     }
 #endif
