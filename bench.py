@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--spp", type=int, default=8)
     ap.add_argument("--box", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fast-weights", action="store_true", help="opt-in fp32 pair weights (RPF_FLAG_FAST_WEIGHTS)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
 
@@ -123,7 +124,8 @@ def main():
     colour0 = planes[2:5].to(torch.float64).contiguous()
     colour = colour0.clone()
     ctx = hip.Context(local_rank)
-    desc = hip.make_desc(W, H_buf, S, boxes=(box,), row_begin=row_begin, row_end=row_end, flags=hip.FLAG_TIMING)
+    flags = hip.FLAG_TIMING | (hip.FLAG_FAST_WEIGHTS if args.fast_weights else 0)
+    desc = hip.make_desc(W, H_buf, S, boxes=(box,), row_begin=row_begin, row_end=row_end, flags=flags)
     stream = torch.cuda.current_stream().cuda_stream
 
     kernel_ms = []
@@ -167,7 +169,7 @@ def main():
         "metric": "RPF Msamples/sec filtered at 1080p×8spp",
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f64+f32 pair weights" if args.fast_weights else "f64", "data": "synthetic",
         "config": {"workload": workload, "image": "%dx%d" % (W, H_total), "rows_per_gpu": args.rows_per_gpu,
                    "mean_nbhd": cnt.sum_nbhd / float(n_own * W), "max_nbhd": cnt.max_nbhd,
                    "beta_map": "REF_GCC11_O3", "degenerate_policy": "REF_ABORT",

@@ -63,7 +63,14 @@ typedef enum rpf_degenerate_policy {
                                 negative variances clamped to 0, NaN colours fall back to the input    */
 } rpf_degenerate_policy;
 
-enum { RPF_FLAG_NONE = 0, RPF_FLAG_TIMING = 1 /* bracket kernels with hipEvents (rpf_query_counters) */ };
+enum {
+    RPF_FLAG_NONE = 0,
+    RPF_FLAG_TIMING = 1,       /* bracket kernels with hipEvents (rpf_query_counters) */
+    RPF_FLAG_FAST_WEIGHTS = 2  /* opt-in: the S x N pair weights of stage 4 (rpf.cpp:637-678) are evaluated in fp32 on
+                                  fp64-formed normalised values, with the hardware exp; everything that decides
+                                  discrete outcomes (membership, bins, MI) is unchanged.  Colours move by ~1e-6
+                                  relative (bar 1e-4).  Default off: fp64 throughout, like the reference. */
+};
 
 typedef struct rpf_desc {
     int32_t W;                         /* pixels per row                                            */

@@ -118,6 +118,7 @@ int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const float *d_plan
     p.row_begin = d->row_begin; p.row_end = d->row_end;
     p.box = box; p.b = (box - 1) / 2;
     p.beta_map = d->beta_map; p.policy = d->degenerate_policy;
+    p.fast_weights = (d->flags & RPF_FLAG_FAST_WEIGHTS) ? 1 : 0;
     {
         const char *sm = std::getenv("RPF_STAGE_MASK"); // timing ablation knob for profiling; results are wrong when set
         p.stage_mask = sm ? std::atoi(sm) : -1;

@@ -20,6 +20,7 @@ struct PassParams {
     int32_t row_begin, row_end;
     int32_t box, b;        // b = (box-1)/2, rpf.cpp:561
     int32_t beta_map, policy;
+    int32_t fast_weights;  // RPF_FLAG_FAST_WEIGHTS: fp32 pair arithmetic in stage 4
     int32_t stage_mask;    // diagnostics only (env RPF_STAGE_MASK): bit0 stats chain, bit1 bins, bit2 MI, bit3 weights; -1 = all
     int32_t nmax;          // box*box*S: capacity of a neighbourhood
     int32_t bmax;          // floor(sqrt(nmax)): max histogram bins per axis

@@ -206,6 +206,103 @@ __device__ __forceinline__ void zero_cells(uint32_t *h, int cells, int lane) {
     }
 }
 
+// ---- stage 3a: normalise, bin ids (sd.h:229-232, mi.cpp:14-16) -----------------------------------------
+// bin ids are bytes packed per lane: sample kk of the lane is byte kk of KW words per column, written to LDS
+// [column][lane][KW] over the (now dead) staging buffer of stage 2.  KD = sample slots handled (the occupied
+// ones when the kernel is specialised on them, else K); holes compute on a dummy value and are masked.
+template <int KD, int KW>
+__device__ __forceinline__ void bins_stage(const PassParams &p, const double *sStat, const uint32_t *sOff, uint32_t *sBinW,
+                                           int lane, int n, int B) {
+    const double dB = (double)B;
+    {
+        uint32_t offk[KD];
+#pragma unroll
+        for (int kk = 0; kk < KD; ++kk) offk[kk] = (lane + kWave * kk < n) ? sOff[lane + kWave * kk] : 0u;
+        // one column: z, t, bin for the lane's K samples, packed into KW words
+        auto do_column = [&](int c, const double (&xv)[KD]) {
+            const double Mc = sStat[c], SDc = sStat[kNDim + c];
+            const double xlo = sStat[2 * kNDim + c], xhi = sStat[3 * kNDim + c];
+            const bool sd0 = (SDc == 0.0);
+            const UDiv dsd = udiv_prepare(SDc);
+            const double lo = sd0 ? 0.0 : udiv(xlo - Mc, dsd); // min_element over z (mi.cpp:47,49)
+            const double hi = sd0 ? 0.0 : udiv(xhi - Mc, dsd); // max_element over z (mi.cpp:48,50)
+            const double range = hi - lo;
+            const bool flat = !(hi != lo);                       // mi.cpp:7 / 28 / 34
+            const UDiv drg = udiv_prepare(range);
+            const bool fast = dsd.fast && (flat || drg.fast);   // wave-uniform
+            uint32_t w[KW];
+#pragma unroll
+            for (int q4 = 0; q4 < KW; ++q4) w[q4] = 0u;
+            if (fast && !sd0 && !flat) {
+                // the common case, straight-line for all K samples of the lane (holes compute on a dummy value
+                // and are masked at the pack), so the K dependent chains interleave
+#pragma unroll
+                for (int kk = 0; kk < KD; ++kk) {
+                    const double a = xv[kk] - Mc;                          // subtractArrays
+                    const double z = udiv_fast(a, dsd);                    // divideArrays, ops.h:48
+                    const double t = udiv_fast(z - lo, drg) * dB;          // mi.cpp:14
+                    int bin = (int)t;
+                    bin = min(bin, B - 1);
+                    bin = max(bin, 0);
+                    bin = (lane + kWave * kk < n) ? bin : 0;
+                    w[kk >> 2] |= (uint32_t)bin << (8 * (kk & 3));
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KD; ++kk) {
+                    if (lane + kWave * kk < n) {
+                        const double a = xv[kk] - Mc;
+                        const double z = sd0 ? 0.0 : a / SDc;
+                        int bin = 0;
+                        if (!flat) {
+                            const double t = (z - lo) / range * dB;
+                            bin = (int)t;
+                            bin = min(bin, B - 1);
+                            bin = max(bin, 0);
+                        }
+                        w[kk >> 2] |= (uint32_t)bin << (8 * (kk & 3));
+                    }
+                }
+            }
+            store_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, w);
+        };
+        if (p.stage_mask & 2) {
+            // the 16 fp32 columns (0,1,5..18) through kPF3 rotating register buffers, gathers kPF3 columns ahead
+            constexpr int kPF3 = 4;
+            float xb[kPF3][KD];
+            auto colidx = [](int i) { return i < 2 ? i : i + 3; };
+            auto issue3 = [&](int i, float (&dst)[KD]) {
+                const float *fplane = p.planes + (uint64_t)colidx(i) * p.plane_stride;
+#pragma unroll
+                for (int kk = 0; kk < KD; ++kk) dst[kk] = fplane[offk[kk]];
+            };
+#pragma unroll
+            for (int u = 0; u < kPF3; ++u) issue3(u, xb[u]);
+#pragma unroll 1
+            for (int i0 = 0; i0 < 16; i0 += kPF3) {
+#pragma unroll
+                for (int u = 0; u < kPF3; ++u) {
+                    double xv[KD];
+#pragma unroll
+                    for (int kk = 0; kk < KD; ++kk) xv[kk] = (double)xb[u][kk];
+                    if (i0 + u + kPF3 < 16) issue3(i0 + u + kPF3, xb[u]);
+                    do_column(colidx(i0 + u), xv);
+                }
+            }
+            // the 3 fp64 colour columns
+            double xc[3][KD];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double *dplane = p.col_in + (uint64_t)c * p.plane_stride;
+#pragma unroll
+                for (int kk = 0; kk < KD; ++kk) xc[c][kk] = dplane[offk[kk]];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) do_column(kColC + c, xc[c]);
+        }
+    }
+}
+
 // One group of G (3 or 4) histograms, straight-line.  For marginals (JOINT = false) histogram u bins column
 // col0+u; for joints it bins (anchor, partner col(u)).  Slots kk < KD-1 are full by definition of KD (= ceil(n/64)),
 // so only the last slot carries the hole mask: `lastkey_ok` lanes exist, the others aim a +0 atomic at `hole`.
@@ -315,7 +412,7 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
 //   K         compile-time bound on samples per lane: K*64 >= nmax ; lane owns samples j = lane + 64*kk
 //   T_IN_LDS  keep the D table in LDS (small neighbourhoods) instead of reading it through L1
 // ------------------------------------------------------------------------------------------------
-template <int K, bool T_IN_LDS>
+template <int K, bool T_IN_LDS, bool FAST>
 __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayout L) {
     constexpr int KW = (K + 3) / 4;          // 32-bit words of bin ids per lane and column
     extern __shared__ __align__(16) unsigned char smem[];
@@ -554,97 +651,22 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
         wsync();
     }
 
-    // ---------------- stage 3a: normalise, bin ids (sd.h:229-232, mi.cpp:14-16) ------------------
-    // bin ids are bytes packed per lane: sample kk of the lane is byte kk of KW words per column, written
-    // to LDS [column][lane][KW] over the (now dead) staging buffer of stage 2.
+    // ---------------- stage 3a: normalise, bin ids: bins_stage() above --------------------------
     const int B = max(1, (int)sqrt((double)n)); // mi.cpp:54
-    const double dB = (double)B;
-    {
-        uint32_t offk[K];
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk) offk[kk] = (lane + kWave * kk < n) ? sOff[lane + kWave * kk] : 0u;
-        // one column: z, t, bin for the lane's K samples, packed into KW words
-        auto do_column = [&](int c, const double (&xv)[K]) {
-            const double Mc = sStat[c], SDc = sStat[kNDim + c];
-            const double xlo = sStat[2 * kNDim + c], xhi = sStat[3 * kNDim + c];
-            const bool sd0 = (SDc == 0.0);
-            const UDiv dsd = udiv_prepare(SDc);
-            const double lo = sd0 ? 0.0 : udiv(xlo - Mc, dsd); // min_element over z (mi.cpp:47,49)
-            const double hi = sd0 ? 0.0 : udiv(xhi - Mc, dsd); // max_element over z (mi.cpp:48,50)
-            const double range = hi - lo;
-            const bool flat = !(hi != lo);                       // mi.cpp:7 / 28 / 34
-            const UDiv drg = udiv_prepare(range);
-            const bool fast = dsd.fast && (flat || drg.fast);   // wave-uniform
-            uint32_t w[KW];
-#pragma unroll
-            for (int q4 = 0; q4 < KW; ++q4) w[q4] = 0u;
-            if (fast && !sd0 && !flat) {
-                // the common case, straight-line for all K samples of the lane (holes compute on a dummy value
-                // and are masked at the pack), so the K dependent chains interleave
-#pragma unroll
-                for (int kk = 0; kk < K; ++kk) {
-                    const double a = xv[kk] - Mc;                          // subtractArrays
-                    const double z = udiv_fast(a, dsd);                    // divideArrays, ops.h:48
-                    const double t = udiv_fast(z - lo, drg) * dB;          // mi.cpp:14
-                    int bin = (int)t;
-                    bin = min(bin, B - 1);
-                    bin = max(bin, 0);
-                    bin = (lane + kWave * kk < n) ? bin : 0;
-                    w[kk >> 2] |= (uint32_t)bin << (8 * (kk & 3));
-                }
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < K; ++kk) {
-                    if (lane + kWave * kk < n) {
-                        const double a = xv[kk] - Mc;
-                        const double z = sd0 ? 0.0 : a / SDc;
-                        int bin = 0;
-                        if (!flat) {
-                            const double t = (z - lo) / range * dB;
-                            bin = (int)t;
-                            bin = min(bin, B - 1);
-                            bin = max(bin, 0);
-                        }
-                        w[kk >> 2] |= (uint32_t)bin << (8 * (kk & 3));
-                    }
-                }
-            }
-            store_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, w);
-        };
-        if (p.stage_mask & 2) {
-            // the 16 fp32 columns (0,1,5..18) through kPF3 rotating register buffers, gathers kPF3 columns ahead
-            constexpr int kPF3 = 4;
-            float xb[kPF3][K];
-            auto colidx = [](int i) { return i < 2 ? i : i + 3; };
-            auto issue3 = [&](int i, float (&dst)[K]) {
-                const float *fplane = p.planes + (uint64_t)colidx(i) * p.plane_stride;
-#pragma unroll
-                for (int kk = 0; kk < K; ++kk) dst[kk] = fplane[offk[kk]];
-            };
-#pragma unroll
-            for (int u = 0; u < kPF3; ++u) issue3(u, xb[u]);
-#pragma unroll 1
-            for (int i0 = 0; i0 < 16; i0 += kPF3) {
-#pragma unroll
-                for (int u = 0; u < kPF3; ++u) {
-                    double xv[K];
-#pragma unroll
-                    for (int kk = 0; kk < K; ++kk) xv[kk] = (double)xb[u][kk];
-                    if (i0 + u + kPF3 < 16) issue3(i0 + u + kPF3, xb[u]);
-                    do_column(colidx(i0 + u), xv);
-                }
-            }
-            // the 3 fp64 colour columns
-            double xc[3][K];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double *dplane = p.col_in + (uint64_t)c * p.plane_stride;
-#pragma unroll
-                for (int kk = 0; kk < K; ++kk) xc[c][kk] = dplane[offk[kk]];
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) do_column(kColC + c, xc[c]);
+    const int kdyn = (n + kWave - 1) / kWave;   // wave-uniform: sample slots kk < kdyn exist
+    if constexpr (K <= 8) {
+        switch (kdyn) {
+        case 1: bins_stage<1, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
+        case 2: if constexpr (K >= 2) bins_stage<2, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
+        case 3: if constexpr (K >= 3) bins_stage<3, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
+        case 4: if constexpr (K >= 4) bins_stage<4, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
+        case 5: if constexpr (K >= 5) bins_stage<5, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
+        case 6: if constexpr (K >= 6) bins_stage<6, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
+        case 7: if constexpr (K >= 7) bins_stage<7, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
+        default: if constexpr (K >= 8) bins_stage<8, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
         }
+    } else {
+        bins_stage<K, KW>(p, sStat, sOff, sBinW, lane, n, B);
     }
     wsync();
     if (p.dbg.bin_hash != nullptr && lane < kNDim) { // debug only: hash in sample order j = lane + 64*kk
@@ -657,7 +679,6 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
 #ifndef RPF_X_SKIPMI
     if (p.stage_mask & 4) {
         const uint64_t *dtab = T_IN_LDS ? sD : p.dfix;
-        const int kdyn = (n + kWave - 1) / kWave; // wave-uniform: sample slots kk < kdyn exist
         if constexpr (K <= 8) {
             // one straight-line instantiation per number of occupied sample slots (and per number of 1-KiB clearing
             // stores): no branch sits between the LDS operations of a histogram group, so they pipeline under
@@ -775,6 +796,35 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             coef[k] = (sd == 0.0) ? (wk[k] * 0.0) * s2 : wk[k] / (sd * sd) * s2;
         }
     }
+    // fast-weights set-up (dead LDS regions: pair sums -> M / 1/SD of the 17 weighted columns; bin ids -> own z rows)
+    double *sFastM = reinterpret_cast<double *>(sPairF);
+    double *sFastI = sFastM + 17;
+    float *sFastZ = reinterpret_cast<float *>(sBinW);
+    float coefz[17];
+    if constexpr (FAST) {
+        const double sigma_c2 = p.seed * p.seed / (1 - wrc) / (1 - wrc);
+        const double inv2sc = 1.0 / (2 * sigma_c2), inv2sp = 1.0 / (2 * (p.sigma_p * p.sigma_p));
+#pragma unroll
+        for (int k = 0; k < 17; ++k) {
+            const double wkk = k < 2 ? 1.0 : (k < 5 ? alpha[k < 5 && k >= 2 ? k - 2 : 0] : beta[k >= 5 ? k - 5 : 0]);
+            coefz[k] = (float)(wkk * (k < 2 ? inv2sp : inv2sc));
+        }
+        wsync();
+        if (lane < 17) {
+            const int col = lane < 5 ? lane : lane + 2;
+            const double sd = sStat[kNDim + col];
+            sFastM[lane] = sStat[col];
+            sFastI[lane] = (sd == 0.0) ? 0.0 : 1.0 / sd; // SD == 0 normalises to z == 0 (ops.h:48)
+        }
+        wsync();
+        for (int t = lane; t < S * 20; t += kWave) {
+            const int i = t / 20, k = t - i * 20;
+            float z = 0.f;
+            if (k < 17) z = (float)((sOwn[i * kNDim + (k < 5 ? k : k + 2)] - sFastM[k]) * sFastI[k]);
+            sFastZ[t] = z;
+        }
+        wsync();
+    }
     bool bad = false;
 #ifndef RPF_X_SKIP4
     for (int i0 = 0; i0 < ((p.stage_mask & 8) ? S : 0); i0 += 8) {
@@ -794,6 +844,7 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             }
         };
         fetch17(lane);
+        if constexpr (!FAST) {
 #pragma unroll 1
         for (int kk = 0; kk < K; ++kk) {
             const int j = lane + kWave * kk;
@@ -821,6 +872,49 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
                     s0[ii] = fma(w, xj[2], s0[ii]);         // rpf.cpp:692 (raw neighbourhood colours)
                     s1[ii] = fma(w, xj[3], s1[ii]);
                     s2[ii] = fma(w, xj[4], s2[ii]);
+                }
+            }
+        }
+        } else {
+            // opt-in RPF_FLAG_FAST_WEIGHTS: per-pair arithmetic in fp32 on z-space values (x-M)/SD that are formed in
+            // fp64 (so large world coordinates do not cancel in fp32), v_exp_f32, fp64 accumulation of the sums.
+            // Filtered colours differ from the fp64 path by ~1e-6 relative (bar: 1e-4).
+#pragma unroll 1
+            for (int kk = 0; kk < K; ++kk) {
+                const int j = lane + kWave * kk;
+                if (j >= n) break;
+                float zj[17];
+                double cj[3];
+                zj[0] = (float)(((double)pf[0] - sFastM[0]) * sFastI[0]);
+                zj[1] = (float)(((double)pf[1] - sFastM[1]) * sFastI[1]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { cj[k] = pc[k]; zj[2 + k] = (float)((pc[k] - sFastM[2 + k]) * sFastI[2 + k]); }
+#pragma unroll
+                for (int k = 0; k < 12; ++k) zj[5 + k] = (float)(((double)pf[2 + k] - sFastM[5 + k]) * sFastI[5 + k]);
+                fetch17(j + kWave);
+#pragma unroll
+                for (int ii = 0; ii < 8; ++ii) {
+                    const int i = i0 + ii;
+                    if (i < S) {
+                        const float *zi = sFastZ + i * 20; // rows padded to 20 floats: five 16-byte reads
+                        float zo[20];
+#pragma unroll
+                        for (int q4 = 0; q4 < 5; ++q4) {
+                            const float4 v = reinterpret_cast<const float4 *>(zi)[q4];
+                            zo[4 * q4] = v.x; zo[4 * q4 + 1] = v.y; zo[4 * q4 + 2] = v.z; zo[4 * q4 + 3] = v.w;
+                        }
+                        float E = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 17; ++k) {
+                            const float d = zo[k] - zj[k];
+                            E = fmaf(d * d, coefz[k], E);
+                        }
+                        const double w = (double)__expf(-E);
+                        sw[ii] += w;
+                        s0[ii] = fma(w, cj[0], s0[ii]);
+                        s1[ii] = fma(w, cj[1], s1[ii]);
+                        s2[ii] = fma(w, cj[2], s2[ii]);
+                    }
                 }
             }
         }
@@ -937,21 +1031,20 @@ __global__ __launch_bounds__(256) void nbhd_reduce_kernel(const int32_t *nbhd, u
     }
 }
 
+template <int K, bool TL, bool FAST>
+hipError_t launch_filter_inst(const PassParams &p, const LdsLayout &L, unsigned grid, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute((const void *)filter_pixel_kernel<K, TL, FAST>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((filter_pixel_kernel<K, TL, FAST>), dim3(grid), dim3(64), L.total, s, p, L);
+    return hipGetLastError();
+}
 template <int K>
 hipError_t launch_filter_k(const PassParams &p, const LdsLayout &L, bool t_in_lds, unsigned grid, hipStream_t s) {
-    hipError_t e;
-    if (t_in_lds) {
-        e = hipFuncSetAttribute((const void *)filter_pixel_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)L.total);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((filter_pixel_kernel<K, true>), dim3(grid), dim3(64), L.total, s, p, L);
-    } else {
-        e = hipFuncSetAttribute((const void *)filter_pixel_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)L.total);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((filter_pixel_kernel<K, false>), dim3(grid), dim3(64), L.total, s, p, L);
+    if (p.fast_weights) {
+        return t_in_lds ? launch_filter_inst<K, true, true>(p, L, grid, s) : launch_filter_inst<K, false, true>(p, L, grid, s);
     }
-    return hipGetLastError();
+    return t_in_lds ? launch_filter_inst<K, true, false>(p, L, grid, s) : launch_filter_inst<K, false, false>(p, L, grid, s);
 }
 
 } // namespace

@@ -18,6 +18,7 @@ OK, E_BADARG, E_HIP, E_NONFINITE, E_NOMEM, E_UNSUPPORTED, E_NODEVICE = range(7)
 BETA_REF_GCC11_O3, BETA_REF_GCC11_O2, BETA_PAPER = 0, 1, 2
 DEGEN_REF_ABORT, DEGEN_EPS = 0, 1
 FLAG_TIMING = 1
+FLAG_FAST_WEIGHTS = 2
 
 EXPORTS = ["rpf_version", "rpf_status_string", "rpf_create", "rpf_destroy", "rpf_last_error", "rpf_filter",
            "rpf_filter_device", "rpf_colour_from_planes_device", "rpf_reduce_device", "rpf_stage_pixel_stats",

@@ -148,6 +148,20 @@ def test_multi_pass_and_pixel_reduction(ctx, hipmod, oracle):
     assert cnt.samples_filtered == W * H * S * 2 and cnt.filter_kernel_launches == 2
 
 
+def test_fast_weights_mode_meets_the_bar(ctx, hipmod, oracle):
+    """RPF_FLAG_FAST_WEIGHTS: fp32 pair weights; every discrete outcome unchanged, colours within 1e-4 rel-L2"""
+    for (W, H, S, mode, sf, sc) in [(24, 16, 8, "clustered", 1e-3, 0.01), (16, 12, 16, "clustered", 1e-3, 0.01),
+                                    (24, 16, 8, "smooth", 0.05, 1e-4)]:
+        planes = fb.synth_planes(W, H, S, seed=11, sigma_f=sf, sigma_c=sc, mode=mode)
+        planes[10:13] += 800.0  # large world coordinates: differences must not be formed in fp32
+        got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, flags=hipmod.FLAG_FAST_WEIGHTS), box=7)
+        want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7))
+        assert (got["nbhd_size"] == want["nbhd_size"]).all() and (got["bin_hash"] == want["bin_hash"]).all()
+        np.testing.assert_allclose(got["beta"], want["beta"], rtol=1e-9, atol=1e-12)
+        r = rel_l2(got["colour"], want["colour"])
+        assert r <= 1e-5, r  # an order of magnitude inside the 1e-4 bar
+
+
 def test_badarg_and_unsupported(ctx, hipmod):
     planes = np.zeros((19, 4, 4, 2), np.float32)
     with pytest.raises(hipmod.RpfError) as e:
