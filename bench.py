@@ -183,6 +183,20 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(torch, planes, n_own, W, S, box, args.cpu_seconds, colour)
+        if not args.fast_weights:
+            # the opt-in fp32 pair-weight mode, measured on the same buffer for information (never `value`)
+            ref = colour.clone()
+            d2 = hip.make_desc(W, H_buf, S, boxes=(box,), row_begin=row_begin, row_end=row_end,
+                               flags=hip.FLAG_TIMING | hip.FLAG_FAST_WEIGHTS)
+            ms = []
+            for _ in range(3):
+                colour.copy_(colour0)
+                ctx.filter_device(d2, planes.data_ptr(), colour.data_ptr(), stream)
+                ms.append(ctx.counters().filter_kernel_ms)
+            torch.cuda.synchronize()
+            rel = float(((colour - ref).norm() / ref.norm()).item())
+            out["fast_weights_f32"] = {"kernel_ms": min(ms), "Msamples_per_s_kernel": n_own * W * S / (min(ms) * 1e-3) / 1e6,
+                                       "rel_l2_vs_f64_path": rel}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
