@@ -160,6 +160,11 @@ int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *desc, int32_t box, c
 /* counters of the most recent rpf_filter / rpf_filter_device / rpf_filter_pass_debug call */
 int32_t rpf_query_counters(rpf_ctx *ctx, rpf_counters *out);
 
+/* visualizeSF (rpf.cpp:37-101, visualization/vis.cpp:34-51): the reference's six debug images, without the EXR
+ * writer: per-pixel mean over the S samples of n0, n1, p0, p1, (pFilm.x, pFilm.y, 0), (pLens.x, pLens.y, 0), each
+ * channel divided by its maximum over the image.  images_out: host, fp64 [6][H][W][3] in that order. */
+int32_t rpf_feature_images(rpf_ctx *ctx, const rpf_desc *desc, const float *planes, double *images_out);
+
 /* device self-test: the kernels divide by wave-uniform divisors with a hoisted reciprocal (3 instructions per
  * quotient); this compares n pseudo-random quotients bit-for-bit with the compiler's IEEE fp64 division.
  * mode 0: operand magnitudes of the filter (2^-40..2^40); mode 1: 2^-600..2^600 (exercises the fallback). */

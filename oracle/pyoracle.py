@@ -68,6 +68,7 @@ def lib():
                                              C.POINTER(Debug), C.POINTER(Result)]
         L.rpf_oracle_pixel_mean.argtypes = [C.POINTER(Desc), C.c_void_p, C.c_void_p, C.c_void_p]
         L.rpf_oracle_pair_table.argtypes = [C.c_void_p, C.c_void_p]
+        L.rpf_oracle_feature_images.argtypes = [C.POINTER(Desc), C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -204,4 +205,12 @@ def pixel_mean(colour, desc, ray_weight=None):
     rw = None if ray_weight is None else np.ascontiguousarray(ray_weight, np.float32)
     out = np.zeros((desc.H, desc.W, 3))
     lib().rpf_oracle_pixel_mean(C.byref(desc), _p(colour), _p(rw), _p(out))
+    return out
+
+
+def feature_images(planes, desc):
+    """visualizeSF: six max-normalised per-pixel-mean images [6, H, W, 3] (n0, n1, p0, p1, pFilm, pLens)"""
+    planes = np.ascontiguousarray(planes, np.float32)
+    out = np.zeros((6, desc.H, desc.W, 3))
+    lib().rpf_oracle_feature_images(C.byref(desc), _p(planes), _p(out))
     return out

@@ -457,3 +457,25 @@ void rpf_oracle_pixel_mean(const rpf_oracle_desc *d, const double *colour, const
                 pixel_rgb[((size_t)y * d->W + x) * 3 + c] = acc / (double)d->S;
             }
 }
+
+/* rpf.cpp:37-101 and vis.cpp:34-51 */
+void rpf_oracle_feature_images(const rpf_oracle_desc *d, const float *planes, double *out) {
+    static const int first_col[6] = {7, 13, 10, 16, 0, 5}; /* n0, n1, p0, p1, pFilm, pLens */
+    static const int ncol[6] = {3, 3, 3, 3, 2, 2};
+    const size_t ps = plane_stride(d), HW = (size_t)d->H * d->W;
+    for (int im = 0; im < 6; ++im) {
+        double *img = out + (size_t)im * HW * 3;
+        double mx[3] = {0, 0, 0}; /* vis.cpp:38 */
+        for (size_t pix = 0; pix < HW; ++pix)
+            for (int c = 0; c < 3; ++c) {
+                double acc = 0; /* BasicRGB sums, rpf.cpp:71-76 */
+                if (c < ncol[im])
+                    for (int s = 0; s < d->S; ++s) acc = acc + (double)planes[(size_t)(first_col[im] + c) * ps + pix * d->S + s];
+                acc = acc / (double)d->S; /* rpf.cpp:80-85 */
+                img[pix * 3 + c] = acc;
+                if (mx[c] < acc) mx[c] = acc; /* std::max, vis.cpp:41-43 */
+            }
+        for (size_t pix = 0; pix < HW; ++pix)
+            for (int c = 0; c < 3; ++c) img[pix * 3 + c] = mx[c] == 0 ? 0 : img[pix * 3 + c] / mx[c]; /* vis.h:32-37 */
+    }
+}

@@ -117,6 +117,12 @@ void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const
 void rpf_oracle_pixel_mean(const rpf_oracle_desc *d, const double *colour, const float *ray_weight,
                            double *pixel_rgb);
 
+/* visualizeSF (rpf.cpp:37-101) + normalizeRGBMatrix (vis.cpp:34-51): six debug images, each [H*W*3] fp64, in the
+ * order I0_Normal (n0), I1_Normal (n1), I0_Position (p0), I1_Position (p1), Film_Position (pFilm.x, pFilm.y, 0),
+ * Lens_Position (pLens.x, pLens.y, 0): per-pixel mean over the S samples, then every channel divided by its
+ * maximum over the image (maximum starts at 0; a zero maximum gives 0, vis.h:32-37). out = 6 images back to back. */
+void rpf_oracle_feature_images(const rpf_oracle_desc *d, const float *planes, double *out);
+
 /* pair order of the 96 MI values (a,b column indices in the 19-vector) */
 void rpf_oracle_pair_table(int32_t a[RPF_O_NPAIR], int32_t b[RPF_O_NPAIR]);
 

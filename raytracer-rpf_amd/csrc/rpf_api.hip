@@ -446,6 +446,24 @@ int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *d, int32_t box, cons
     return RPF_OK;
 }
 
+int32_t rpf_feature_images(rpf_ctx *ctx, const rpf_desc *d, const float *planes, double *images_out) {
+    int32_t st = validate(ctx, d, false);
+    if (st) return st;
+    if (!planes || !images_out) return fail(ctx, RPF_E_BADARG, "NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t ps = (size_t)d->W * d->H * d->S, HW = (size_t)d->W * d->H;
+    if ((st = ensure(ctx, ctx->d_planes, ctx->cap_planes, kNDim * ps * sizeof(float)))) return st;
+    if ((st = ensure(ctx, ctx->d_dbg[1], ctx->cap_dbg[1], (18 * HW + 18) * sizeof(double)))) return st;
+    double *d_img = (double *)ctx->d_dbg[1];
+    unsigned long long *d_max = (unsigned long long *)(d_img + 18 * HW);
+    HIP_TRY(hipMemcpyAsync(ctx->d_planes, planes, kNDim * ps * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_feature_images(ctx->d_planes, d->W, d->H, d->S, d_img, d_max, s));
+    HIP_TRY(hipMemcpyAsync(images_out, d_img, 18 * HW * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RPF_OK;
+}
+
 int32_t rpf_selftest_udiv(rpf_ctx *ctx, uint64_t n, uint64_t seed, int32_t mode, uint64_t *mismatches) {
     if (!ctx || !mismatches) return RPF_E_BADARG;
     HIP_TRY(hipSetDevice(ctx->device));

@@ -53,6 +53,7 @@ hipError_t launch_reduce(const double *colour, const float *ray_weight, float *s
                          int H, int S, hipStream_t s);
 hipError_t launch_nbhd_reduce(const int32_t *nbhd, int W, int row_begin, int row_end, unsigned long long *out2,
                               hipStream_t s);
+hipError_t launch_feature_images(const float *planes, int W, int H, int S, double *out, unsigned long long *maxbits, hipStream_t s);
 int max_lds_per_block();
 hipError_t launch_udiv_selftest(uint64_t n, uint64_t seed, int mode, unsigned long long *d_mismatch, hipStream_t s);
 

@@ -1011,6 +1011,34 @@ __global__ __launch_bounds__(256) void reduce_kernel(const double *colour, const
     }
 }
 
+// visualizeSF (rpf.cpp:37-101): per-pixel mean of a feature triple over the S samples (in-order fp64 sum) and the
+// per-channel image maximum (vis.cpp:38-45; the maximum starts at 0, so only positive means can raise it and the
+// bit pattern of a positive double orders like an unsigned integer)
+__global__ __launch_bounds__(256) void feature_mean_kernel(const float *planes, uint64_t ps, uint64_t HW, int S,
+                                                            double *out, unsigned long long *maxbits) {
+    const int first_col[6] = {7, 13, 10, 16, 0, 5}, ncol[6] = {3, 3, 3, 3, 2, 2};
+    const uint64_t pix = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const int im = blockIdx.y;
+    if (pix >= HW) return;
+    for (int c = 0; c < 3; ++c) {
+        double acc = 0.0;
+        if (c < ncol[im]) {
+            const float *src = planes + (uint64_t)(first_col[im] + c) * ps + pix * S;
+            for (int s = 0; s < S; ++s) acc = acc + (double)src[s];
+        }
+        acc = acc / (double)S;
+        out[((uint64_t)im * HW + pix) * 3 + c] = acc;
+        if (acc > 0.0) atomicMax(&maxbits[im * 3 + c], (unsigned long long)__double_as_longlong(acc));
+    }
+}
+__global__ __launch_bounds__(256) void feature_normalise_kernel(double *out, uint64_t HW, const unsigned long long *maxbits) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 6 * HW * 3) return;
+    const int im = (int)(i / (HW * 3)), c = (int)(i % 3);
+    const double mx = __longlong_as_double((long long)maxbits[im * 3 + c]);
+    out[i] = (mx == 0.0) ? 0.0 : out[i] / mx; // vis.h:32-37
+}
+
 __global__ __launch_bounds__(256) void nbhd_reduce_kernel(const int32_t *nbhd, uint64_t begin, uint64_t end,
                                                            unsigned long long *out2) {
     uint64_t i = begin + (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1140,6 +1168,15 @@ hipError_t launch_reduce(const double *colour, const float *ray_weight, float *s
     const uint64_t HW = (uint64_t)H * W;
     hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, s, colour, ray_weight,
                        sample_rgb, pixel_rgb, W, H, S);
+    return hipGetLastError();
+}
+
+hipError_t launch_feature_images(const float *planes, int W, int H, int S, double *out, unsigned long long *maxbits, hipStream_t s) {
+    const uint64_t HW = (uint64_t)H * W;
+    hipError_t e = hipMemsetAsync(maxbits, 0, 18 * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(feature_mean_kernel, dim3((unsigned)((HW + 255) / 256), 6), dim3(256), 0, s, planes, HW * S, HW, S, out, maxbits);
+    hipLaunchKernelGGL(feature_normalise_kernel, dim3((unsigned)((18 * HW + 255) / 256)), dim3(256), 0, s, out, HW, maxbits);
     return hipGetLastError();
 }
 

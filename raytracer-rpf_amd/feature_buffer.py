@@ -200,3 +200,44 @@ def planes_to_aos(planes):
 def halo_rows(box):
     """rows of neighbouring slabs a row-tiled rank needs (rpf.cpp:561: b = (box-1)/2)."""
     return (box - 1) // 2
+
+
+# ---- on-disk feature buffers (".rpfb") -------------------------------------------------------------------
+# The reference has no file format for its per-sample buffers (they live on Render()'s stack, rpf.cpp:745).
+# This one makes the bench/test workloads and captured pbrt buffers replayable:
+#   64-byte little-endian header: magic "RPFB", u32 version (1), u32 W, u32 H, u32 S, u32 ndim (19),
+#   u32 dtype (0 = fp32), u32 flags (bit 0: a ray-weight plane follows), 8 reserved u32
+#   then planes [ndim][H][W][S] fp32, then (flag bit 0) ray_weight [H][W][S] fp32.
+import struct
+
+RPFB_MAGIC = b"RPFB"
+
+
+def save_rpfb(path, planes, ray_weight=None):
+    planes = np.ascontiguousarray(planes, np.float32)
+    nd, H, W, S = planes.shape
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4s7I8I", RPFB_MAGIC, 1, W, H, S, nd, 0, 1 if ray_weight is not None else 0, *([0] * 8)))
+        f.write(planes.tobytes())
+        if ray_weight is not None:
+            rw = np.ascontiguousarray(ray_weight, np.float32)
+            assert rw.shape == (H, W, S)
+            f.write(rw.tobytes())
+
+
+def load_rpfb(path, mmap=False):
+    """returns (planes [ndim,H,W,S] f32, ray_weight [H,W,S] f32 or None); mmap=True maps large files lazily"""
+    with open(path, "rb") as f:
+        hdr = f.read(64)
+    magic, ver, W, H, S, nd, dtype, flags = struct.unpack("<4s7I", hdr[:32])
+    if magic != RPFB_MAGIC or ver != 1 or dtype != 0:
+        raise ValueError("%s: not an RPFB v1 fp32 file" % path)
+    n = nd * H * W * S
+    if mmap:
+        planes = np.memmap(path, np.float32, "r", 64, (nd, H, W, S))
+        rw = np.memmap(path, np.float32, "r", 64 + 4 * n, (H, W, S)) if flags & 1 else None
+    else:
+        data = np.fromfile(path, np.float32, offset=64)
+        planes = data[:n].reshape(nd, H, W, S)
+        rw = data[n:n + H * W * S].reshape(H, W, S) if flags & 1 else None
+    return planes, rw

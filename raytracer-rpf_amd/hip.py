@@ -22,7 +22,7 @@ FLAG_FAST_WEIGHTS = 2
 
 EXPORTS = ["rpf_version", "rpf_status_string", "rpf_create", "rpf_destroy", "rpf_last_error", "rpf_filter",
            "rpf_filter_device", "rpf_colour_from_planes_device", "rpf_reduce_device", "rpf_stage_pixel_stats",
-           "rpf_filter_pass_debug", "rpf_query_counters", "rpf_lds_bytes_required", "rpf_selftest_udiv"]
+           "rpf_filter_pass_debug", "rpf_query_counters", "rpf_lds_bytes_required", "rpf_selftest_udiv", "rpf_feature_images"]
 
 
 class Desc(C.Structure):
@@ -86,6 +86,7 @@ def load():
                                             C.c_void_p, C.POINTER(Debug)]
         L.rpf_query_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
         L.rpf_selftest_udiv.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_uint64)]
+        L.rpf_feature_images.argtypes = [C.c_void_p, C.POINTER(Desc), C.c_void_p, C.c_void_p]
         L.rpf_lds_bytes_required.restype = C.c_int64
         L.rpf_lds_bytes_required.argtypes = [C.c_int32, C.c_int32]
         _lib = L
@@ -189,6 +190,12 @@ class Context:
         d.update(colour=out, status=st, nonfinite_pixels=c.nonfinite_pixels, first_bad_pixel=c.first_bad_pixel,
                  sum_nbhd=c.sum_nbhd, max_nbhd=c.max_nbhd, filter_kernel_ms=c.filter_kernel_ms)
         return d
+
+    def feature_images(self, planes, desc):
+        planes = np.ascontiguousarray(planes, np.float32)
+        out = np.empty((6, desc.H, desc.W, 3))
+        self._check(self._L.rpf_feature_images(self._h, C.byref(desc), _p(planes), _p(out)))
+        return out
 
     def selftest_udiv(self, n, seed=1, mode=0):
         m = C.c_uint64(0)

@@ -87,3 +87,37 @@ def test_aos_soa_round_trip():
     assert aos.shape == (7, 5, 3, 19) and aos.dtype == np.float64
     assert aos[2, 4, 1, 10] == planes[10, 4, 2, 1]
     assert np.array_equal(fb.aos_to_planes(aos), planes)
+
+
+def test_rpfb_wire_format_round_trip(tmp_path):
+    from raytracer_rpf_amd import feature_buffer as fb
+    planes = fb.synth_planes(9, 6, 4, seed=2)
+    rw = np.random.default_rng(0).random((6, 9, 4)).astype(np.float32)
+    path = str(tmp_path / "buf.rpfb")
+    fb.save_rpfb(path, planes, rw)
+    assert os.path.getsize(path) == 64 + planes.nbytes + rw.nbytes
+    p2, r2 = fb.load_rpfb(path)
+    assert np.array_equal(p2, planes) and np.array_equal(r2, rw)
+    p3, r3 = fb.load_rpfb(path, mmap=True)
+    assert np.array_equal(np.asarray(p3), planes) and np.array_equal(np.asarray(r3), rw)
+    fb.save_rpfb(path, planes)
+    p4, r4 = fb.load_rpfb(path)
+    assert r4 is None and np.array_equal(p4, planes)
+    with open(path, "r+b") as f:
+        f.write(b"XXXX")
+    with pytest.raises(ValueError):
+        fb.load_rpfb(path)
+
+
+def test_oracle_feature_images_follow_visualizeSF(oracle):
+    """hand check of rpf.cpp:71-85 + vis.cpp:34-51 on a 2x1 image"""
+    planes = np.zeros((19, 1, 2, 2), np.float32)
+    planes[7, 0, 0] = [1.0, 3.0]    # n0.x pixel 0: mean 2
+    planes[7, 0, 1] = [4.0, 4.0]    # n0.x pixel 1: mean 4 -> max
+    planes[8, 0, :] = -1.0          # n0.y negative everywhere: max stays 0 -> 0
+    planes[0, 0, 0] = [0.25, 0.75]  # pFilm.x
+    planes[0, 0, 1] = [1.25, 1.75]
+    img = oracle.feature_images(planes, oracle.make_desc(2, 1, 2))
+    assert img.shape == (6, 1, 2, 3)
+    assert list(img[0, 0, :, 0]) == [0.5, 1.0] and (img[0, 0, :, 1] == 0).all()
+    assert list(img[4, 0, :, 0]) == [0.5 / 1.5, 1.0] and (img[4, 0, :, 2] == 0).all()

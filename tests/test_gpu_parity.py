@@ -162,6 +162,18 @@ def test_fast_weights_mode_meets_the_bar(ctx, hipmod, oracle):
         assert r <= 1e-5, r  # an order of magnitude inside the 1e-4 bar
 
 
+def test_feature_images_bit_exact(ctx, hipmod, oracle):
+    """visualizeSF (rpf.cpp:37-101): the six max-normalised per-pixel-mean feature images, bit for bit"""
+    W, H, S = 33, 17, 8
+    planes = fb.synth_planes(W, H, S, seed=8)
+    planes[13:19, :, :, ::2] = 0.0   # missed second hits: zeros among the samples (SURVEY F10)
+    planes[7] = -np.abs(planes[7])   # an all-negative channel: its maximum stays 0 -> the channel normalises to 0
+    got = ctx.feature_images(planes, hipmod.make_desc(W, H, S))
+    want = oracle.feature_images(planes, oracle.make_desc(W, H, S))
+    assert np.array_equal(got, want)
+    assert (got[0, ..., 0] == 0).all() and got[2].max() == 1.0
+
+
 def test_badarg_and_unsupported(ctx, hipmod):
     planes = np.zeros((19, 4, 4, 2), np.float32)
     with pytest.raises(hipmod.RpfError) as e:
