@@ -1114,6 +1114,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     uint32_t cells = (uint32_t)bmax * (uint32_t)bmax;
     if (K <= 8 && cells < 512u) cells = 512u; // mi_stage clears with unconditional 1-KiB stores
     o += align_up(cells * 4u, 16);
+    if (const char *e = std::getenv("RPF_LDS_PAD")) o += (uint32_t)std::atoi(e); // occupancy experiment knob
     L.total = o;
     return L;
 }
