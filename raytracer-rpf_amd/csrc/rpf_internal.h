@@ -12,7 +12,8 @@ constexpr int kNFeat = RPF_NFEAT; // 12
 constexpr int kNPair = RPF_NPAIR; // 96
 constexpr int kColP = 0, kColC = 2, kColR = 5, kColF = 7;
 constexpr int kWave = 64;
-constexpr int kStageChunk = 64; // samples staged per step of the in-order (reference-order) sums
+constexpr int kStageChunk = 64; // samples gathered per step of the in-order (reference-order) sums
+constexpr int kStageHalf = 32;  // ... and staged through LDS this many at a time
 
 // everything one pass needs, passed by value to the kernels
 struct PassParams {

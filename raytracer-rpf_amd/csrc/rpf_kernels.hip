@@ -206,11 +206,68 @@ __device__ __forceinline__ void zero_cells(uint32_t *h, int cells, int lane) {
     }
 }
 
+// ---- bin-id storage of one pixel ---------------------------------------------------------------------------
+// PACK5 (kernels with K <= 8, where B = floor(sqrt(N)) <= 22): sample slots 0..5 of a lane are 5-bit fields of ONE
+// 32-bit word per (column, lane) -- [19][64] words -- and slot 6 is a byte in a side array [19][64] behind them:
+// 6 KiB per pixel instead of 9.5, which is what lets 12 single-wave workgroups share a CU's LDS.
+// Otherwise (large neighbourhoods): one byte per slot in KW words per (column, lane).
+template <int KW, bool PACK5>
+struct BinIds {
+    uint32_t w[PACK5 ? 1 : KW];
+    uint32_t b6;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < (PACK5 ? 1 : KW); ++i) w[i] = 0u;
+        b6 = 0u;
+    }
+    __device__ __forceinline__ void set(int kk, uint32_t bin) { // kk is a compile-time constant at every call site
+        if constexpr (PACK5) {
+            if (kk < 6) w[0] |= bin << (5 * kk); else b6 = bin;
+        } else {
+            w[kk >> 2] |= bin << (8 * (kk & 3));
+        }
+    }
+    __device__ __forceinline__ uint32_t get(int kk) const {
+        if constexpr (PACK5) return kk < 6 ? ((w[0] >> (5 * kk)) & 31u) : b6;
+        else return (w[kk >> 2] >> (8 * (kk & 3))) & 0xffu;
+    }
+};
+template <int KD, int KW, bool PACK5>
+__device__ __forceinline__ void store_bins(uint32_t *sBinW, int c, int lane, const BinIds<KW, PACK5> &b) {
+    if constexpr (PACK5) {
+        sBinW[c * kWave + lane] = b.w[0];
+        if (KD > 6) reinterpret_cast<uint8_t *>(sBinW + kNDim * kWave)[c * kWave + lane] = (uint8_t)b.b6;
+    } else {
+        store_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, b.w);
+    }
+}
+template <int KD, int KW, bool PACK5>
+__device__ __forceinline__ void load_bins(const uint32_t *sBinW, int c, int lane, BinIds<KW, PACK5> &b) {
+    if constexpr (PACK5) {
+        b.w[0] = sBinW[c * kWave + lane];
+        b.b6 = (KD > 6) ? (uint32_t) reinterpret_cast<const uint8_t *>(sBinW + kNDim * kWave)[c * kWave + lane] : 0u;
+    } else {
+        load_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, b.w);
+        b.b6 = 0u;
+    }
+}
+// bin id of sample j = lane + 64*slot (debug hash only)
+template <int KW, bool PACK5>
+__device__ __forceinline__ uint32_t bin_of_sample(const uint32_t *sBinW, int c, int j) {
+    const int ln = j & 63, slot = j >> 6;
+    if constexpr (PACK5) {
+        if (slot < 6) return (sBinW[c * kWave + ln] >> (5 * slot)) & 31u;
+        return reinterpret_cast<const uint8_t *>(sBinW + kNDim * kWave)[c * kWave + ln];
+    } else {
+        return reinterpret_cast<const uint8_t *>(sBinW + ((size_t)c * kWave + ln) * KW)[slot];
+    }
+}
+
 // ---- stage 3a: normalise, bin ids (sd.h:229-232, mi.cpp:14-16) -----------------------------------------
 // bin ids are bytes packed per lane: sample kk of the lane is byte kk of KW words per column, written to LDS
 // [column][lane][KW] over the (now dead) staging buffer of stage 2.  KD = sample slots handled (the occupied
 // ones when the kernel is specialised on them, else K); holes compute on a dummy value and are masked.
-template <int KD, int KW>
+template <int KD, int KW, bool PACK5>
 __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sStat, const uint32_t *sOff, uint32_t *sBinW,
                                            int lane, int n, int B) {
     const double dB = (double)B;
@@ -230,9 +287,8 @@ __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sS
             const bool flat = !(hi != lo);                       // mi.cpp:7 / 28 / 34
             const UDiv drg = udiv_prepare(range);
             const bool fast = dsd.fast && (flat || drg.fast);   // wave-uniform
-            uint32_t w[KW];
-#pragma unroll
-            for (int q4 = 0; q4 < KW; ++q4) w[q4] = 0u;
+            BinIds<KW, PACK5> w;
+            w.clear();
             if (fast && !sd0 && !flat) {
                 // the common case, straight-line for all K samples of the lane (holes compute on a dummy value
                 // and are masked at the pack), so the K dependent chains interleave
@@ -245,7 +301,7 @@ __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sS
                     bin = min(bin, B - 1);
                     bin = max(bin, 0);
                     bin = (lane + kWave * kk < n) ? bin : 0;
-                    w[kk >> 2] |= (uint32_t)bin << (8 * (kk & 3));
+                    w.set(kk, (uint32_t)bin);
                 }
             } else {
 #pragma unroll
@@ -260,11 +316,11 @@ __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sS
                             bin = min(bin, B - 1);
                             bin = max(bin, 0);
                         }
-                        w[kk >> 2] |= (uint32_t)bin << (8 * (kk & 3));
+                        w.set(kk, (uint32_t)bin);
                     }
                 }
             }
-            store_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, w);
+            store_bins<KD, KW, PACK5>(sBinW, c, lane, w);
         };
         if (p.stage_mask & 2) {
             // the 16 fp32 columns (0,1,5..18) through kPF3 rotating register buffers, gathers kPF3 columns ahead
@@ -307,7 +363,7 @@ __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sS
 // col0+u; for joints it bins (anchor, partner col(u)).  Slots kk < KD-1 are full by definition of KD (= ceil(n/64)),
 // so only the last slot carries the hole mask: `lastkey_ok` lanes exist, the others aim a +0 atomic at `hole`.
 // FULL = false (large neighbourhoods, KD = K): every slot carries its own mask (lane + 64*kk < n).
-template <int KD, int KW, int ZN, int G, bool JOINT, bool FULL>
+template <int KD, int KW, int ZN, int G, bool JOINT, bool FULL, bool PACK5>
 __device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, int lane, int n,
                                          const int (&cols)[4], const uint32_t (&akey)[KD], bool last_ok, uint32_t hole,
                                          int cells, uint64_t (&acc4)[4]) {
@@ -317,11 +373,11 @@ __device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist,
 #pragma unroll
     for (int u = 0; u <= G; ++u) {
         if (u < G) {
-            uint32_t w[KW];
-            load_words<KW>(sBinW + ((size_t)cols[u] * kWave + lane) * KW, w);
+            BinIds<KW, PACK5> w;
+            load_bins<KD, KW, PACK5>(sBinW, cols[u], lane, w);
 #pragma unroll
             for (int kk = 0; kk < KD; ++kk) {
-                uint32_t key = (w[kk >> 2] >> (8 * (kk & 3))) & 0xffu;
+                uint32_t key = w.get(kk);
                 if (JOINT) key += akey[kk];                                  // mi.cpp:39
                 if (FULL) {
                     if (kk == KD - 1) key = last_ok ? key : hole;
@@ -347,7 +403,7 @@ __device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist,
     for (int u = G; u < 4; ++u) acc4[u] = 0ull;
 }
 
-template <int KD, int KW, int ZN, bool FULL>
+template <int KD, int KW, int ZN, bool FULL, bool PACK5>
 __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, uint64_t *sHXf,
                                          uint64_t *sPairF, int lane, int n, int B) {
     const int ncell2 = B * B;
@@ -364,14 +420,14 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
     for (int c0 = 0; c0 < 16; c0 += 4) {
         uint64_t acc4[4];
         const int cols[4] = {c0, c0 + 1, c0 + 2, c0 + 3};
-        mi_group<KD, KW, ZN, 4, false, FULL>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole1, B, acc4);
+        mi_group<KD, KW, ZN, 4, false, FULL, PACK5>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole1, B, acc4);
         const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
         if ((lane & 15) == 0) sHXf[c0 + xl::slot4(lane)] = tot;
     }
     {
         uint64_t acc4[4];
         const int cols[4] = {16, 17, 18, 18};
-        mi_group<KD, KW, ZN, 3, false, FULL>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole1, B, acc4);
+        mi_group<KD, KW, ZN, 3, false, FULL, PACK5>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole1, B, acc4);
         const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
         if ((lane & 15) == 0 && xl::slot4(lane) < 3) sHXf[16 + xl::slot4(lane)] = tot;
     }
@@ -382,10 +438,10 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
         const int acol = g < 2 ? kColR + g : (g < 4 ? kColP + (g - 2) : kColC + (g - 4));
         const int l = g < 2 ? g : 2 + (g - 2); // r0,r1 -> 0,1 ; p0,p1 -> 2,3
         {
-            uint32_t w[KW];
-            load_words<KW>(sBinW + ((size_t)acol * kWave + lane) * KW, w);
+            BinIds<KW, PACK5> w;
+            load_bins<KD, KW, PACK5>(sBinW, acol, lane, w);
 #pragma unroll
-            for (int kk = 0; kk < KD; ++kk) akey[kk] = ((w[kk >> 2] >> (8 * (kk & 3))) & 0xffu) * (uint32_t)B;
+            for (int kk = 0; kk < KD; ++kk) akey[kk] = w.get(kk) * (uint32_t)B;
         }
         // pair index in ComputeCFWeights call order (rpf.cpp:416-442)
         auto pair_index = [&](int i) { return g < 4 ? (i < 12 ? i * 4 + l : 48 + (i - 12) * 16 + l) : 48 + (g - 4) * 16 + 4 + i; };
@@ -393,14 +449,14 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
         for (int i0 = 0; i0 < 12; i0 += 4) { // partners f0..f11
             uint64_t acc4[4];
             const int cols[4] = {kColF + i0, kColF + i0 + 1, kColF + i0 + 2, kColF + i0 + 3};
-            mi_group<KD, KW, ZN, 4, true, FULL>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole2, ncell2, acc4);
+            mi_group<KD, KW, ZN, 4, true, FULL, PACK5>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole2, ncell2, acc4);
             const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
             if ((lane & 15) == 0) sPairF[pair_index(i0 + xl::slot4(lane))] = tot;
         }
         if (g < 4) { // partners c0..c2 (wave-uniform branch)
             uint64_t acc4[4];
             const int cols[4] = {kColC, kColC + 1, kColC + 2, kColC + 2};
-            mi_group<KD, KW, ZN, 3, true, FULL>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole2, ncell2, acc4);
+            mi_group<KD, KW, ZN, 3, true, FULL, PACK5>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole2, ncell2, acc4);
             const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
             if ((lane & 15) == 0 && xl::slot4(lane) < 3) sPairF[pair_index(12 + xl::slot4(lane))] = tot;
         }
@@ -413,17 +469,18 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
 //   T_IN_LDS  keep the D table in LDS (small neighbourhoods) instead of reading it through L1
 // ------------------------------------------------------------------------------------------------
 template <int K, bool T_IN_LDS, bool FAST>
-__global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayout L) {
-    constexpr int KW = (K + 3) / 4;          // 32-bit words of bin ids per lane and column
+__global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLayout L) {
+    constexpr int KW = (K + 3) / 4;          // 32-bit words of byte-packed bin ids per lane and column (K > 8)
+    constexpr bool PACK5 = (K <= 8);         // 5-bit packing, see BinIds
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *sD = reinterpret_cast<uint64_t *>(smem + L.off_T); // D[c] = T[c+1]-T[c], 2^-44 fixed point
     double *sStat = reinterpret_cast<double *>(smem + L.off_stat); // M[19], SD[19], xmin[19], xmax[19]
     uint64_t *sHXf = reinterpret_cast<uint64_t *>(smem + L.off_hx);     // sum_i T[hx_i] per column (fixed point)
     uint64_t *sPairF = reinterpret_cast<uint64_t *>(smem + L.off_pair); // sum_ij T[J_ij] per pair (fixed point)
-    double *sMI = reinterpret_cast<double *>(smem + L.off_mi);     // 96 MI values
+    double *sMI = reinterpret_cast<double *>(smem + L.off_pair);   // 96 MI values, in place over the pair sums
     double *sOwn = reinterpret_cast<double *>(smem + L.off_own);   // raw own samples [S][19]
     uint32_t *sOff = reinterpret_cast<uint32_t *>(smem + L.off_off);
-    double *sStage = reinterpret_cast<double *>(smem + L.off_union);    // [19][kStageChunk+1] (aliases bins)
+    double *sStage = reinterpret_cast<double *>(smem + L.off_union);    // [19][kStageHalf+1] (aliases bins)
     uint32_t *sBinW = reinterpret_cast<uint32_t *>(smem + L.off_union); // bin ids [19][64][KW] words (K > 8)
     uint32_t *sHist = reinterpret_cast<uint32_t *>(smem + L.off_hist);
 
@@ -543,7 +600,7 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
 
     // ---------------- stage 2: mean / std over the neighbourhood, reference order ---------------
     // Chunks of 64 samples: lane t gathers all 19 values of sample j0+t (the next chunk is already in
-    // flight in registers), stages them as doubles [column][t] in LDS, then lanes 0..18 run the in-order
+    // flight in registers), stages them (two halves of 32) as doubles [column][t] in LDS, then lanes 0..18 run the in-order
     // sum(x) chain of column `lane` and lanes 32..50 the sum(x*x) chain of column `lane-32`.
     // The per-column min / max of x ride along (order independent): z = (x-M)/SD is monotone in x, so
     // min z = z(min x) and max z = z(max x) exactly, which is all mi.cpp:47-50 needs.
@@ -576,13 +633,11 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             if (lane < cnt) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    sStage[(i < 2 ? i : i + 3) * (kStageChunk + 1) + lane] = (double)vf[i];
                     fmn[i] = fminf(fmn[i], vf[i]);
                     fmx[i] = fmaxf(fmx[i], vf[i]);
                 }
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    sStage[(kColC + i) * (kStageChunk + 1) + lane] = vd[i];
                     cmn[i] = fmin(cmn[i], vd[i]);
                     cmx[i] = fmax(cmx[i], vd[i]);
                 }
@@ -593,30 +648,42 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
                     for (int i = 0; i < 3; ++i) sOwn[(j0 + lane) * kNDim + kColC + i] = vd[i];
                 }
             }
-            wsync();
-            fetch(j0 + kStageChunk + lane); // next chunk's gathers overlap the serial chains below
-            if (chain) {
-                const double *src = sStage + myc * (kStageChunk + 1);
-                if (cnt == kStageChunk) { // full chunk: LDS reads issue 16 at a time, only the adds are serial
+            // the 64 gathered samples go through the LDS staging buffer 32 at a time ([19][33] doubles: 5 KiB)
 #pragma unroll
-                    for (int h = 0; h < kStageChunk; h += 16) {
-                        double v[16];
+            for (int hf = 0; hf < 2; ++hf) {
+                const int cnth = min(kStageHalf, cnt - hf * kStageHalf); // wave-uniform, may be <= 0
+                const int t = lane - hf * kStageHalf;
+                if (t >= 0 && t < cnth) {
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) v[t] = src[h + t];
-                        if (is_sq) {
+                    for (int i = 0; i < 16; ++i) sStage[(i < 2 ? i : i + 3) * (kStageHalf + 1) + t] = (double)vf[i];
 #pragma unroll
-                            for (int t = 0; t < 16; ++t) v[t] = v[t] * v[t];        // ops.h:138 multiplyArrays
-                        }
-#pragma unroll
-                        for (int t = 0; t < 16; ++t) acc = acc + v[t];              // ops.h:121 / 138 sumArrays
-                    }
-                } else if (!is_sq) {
-                    for (int t = 0; t < cnt; ++t) acc = acc + src[t];
-                } else {
-                    for (int t = 0; t < cnt; ++t) { const double v = src[t]; acc = acc + v * v; }
+                    for (int i = 0; i < 3; ++i) sStage[(kColC + i) * (kStageHalf + 1) + t] = vd[i];
                 }
+                wsync();
+                if (hf == 1) fetch(j0 + kStageChunk + lane); // next chunk's gathers overlap the serial chains below
+                if (chain && cnth > 0) {
+                    const double *src = sStage + myc * (kStageHalf + 1);
+                    if (cnth == kStageHalf) { // full half: LDS reads issue 16 at a time, only the adds are serial
+#pragma unroll
+                        for (int h = 0; h < kStageHalf; h += 16) {
+                            double v[16];
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) v[q] = src[h + q];
+                            if (is_sq) {
+#pragma unroll
+                                for (int q = 0; q < 16; ++q) v[q] = v[q] * v[q];    // ops.h:138 multiplyArrays
+                            }
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) acc = acc + v[q];          // ops.h:121 / 138 sumArrays
+                        }
+                    } else if (!is_sq) {
+                        for (int q = 0; q < cnth; ++q) acc = acc + src[q];
+                    } else {
+                        for (int q = 0; q < cnth; ++q) { const double v = src[q]; acc = acc + v * v; }
+                    }
+                }
+                wsync();
             }
-            wsync();
         }
         const double sq = __shfl(acc, (lane & 31) + 32, 64);
         const double dn = (double)n;
@@ -656,23 +723,22 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
     const int kdyn = (n + kWave - 1) / kWave;   // wave-uniform: sample slots kk < kdyn exist
     if constexpr (K <= 8) {
         switch (kdyn) {
-        case 1: bins_stage<1, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
-        case 2: if constexpr (K >= 2) bins_stage<2, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
-        case 3: if constexpr (K >= 3) bins_stage<3, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
-        case 4: if constexpr (K >= 4) bins_stage<4, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
-        case 5: if constexpr (K >= 5) bins_stage<5, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
-        case 6: if constexpr (K >= 6) bins_stage<6, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
-        case 7: if constexpr (K >= 7) bins_stage<7, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
-        default: if constexpr (K >= 8) bins_stage<8, KW>(p, sStat, sOff, sBinW, lane, n, B); break;
+        case 1: bins_stage<1, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
+        case 2: if constexpr (K >= 2) bins_stage<2, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
+        case 3: if constexpr (K >= 3) bins_stage<3, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
+        case 4: if constexpr (K >= 4) bins_stage<4, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
+        case 5: if constexpr (K >= 5) bins_stage<5, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
+        case 6: if constexpr (K >= 6) bins_stage<6, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
+        case 7: if constexpr (K >= 7) bins_stage<7, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
+        default: if constexpr (K >= 8) bins_stage<8, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
         }
     } else {
-        bins_stage<K, KW>(p, sStat, sOff, sBinW, lane, n, B);
+        bins_stage<K, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B);
     }
     wsync();
-    if (p.dbg.bin_hash != nullptr && lane < kNDim) { // debug only: hash in sample order j = lane + 64*kk
+    if (p.dbg.bin_hash != nullptr && lane < kNDim) { // debug only: hash in sample order j = lane + 64*slot
         uint32_t h = 2166136261u;
-        const uint8_t *bytes = reinterpret_cast<const uint8_t *>(sBinW + (size_t)lane * kWave * KW);
-        for (int j = 0; j < n; ++j) h = fnv1a_u16(h, bytes[(j & 63) * (KW * 4) + (j >> 6)]);
+        for (int j = 0; j < n; ++j) h = fnv1a_u16(h, bin_of_sample<KW, PACK5>(sBinW, lane, j));
         p.dbg.bin_hash[pix * kNDim + lane] = h;
     }
     // ---------------- stage 3b: histograms -> mutual information: mi_stage() above ------------
@@ -685,8 +751,8 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             // counted lgkmcnt waits
 #define RPF_MI_CASE(KD_)                                                                                     \
     if constexpr (K >= KD_) {                                                                                \
-        if (B * B > 256) mi_stage<KD_, KW, 2, true>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);                 \
-        else mi_stage<KD_, KW, 1, true>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);                             \
+        if (B * B > 256) mi_stage<KD_, KW, 2, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);                 \
+        else mi_stage<KD_, KW, 1, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);                             \
     }
             switch (kdyn) {
             case 1: RPF_MI_CASE(1) break;
@@ -700,7 +766,7 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             }
 #undef RPF_MI_CASE
         } else {
-            mi_stage<K, KW, 0, false>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);
+            mi_stage<K, KW, 0, false, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);
         }
     }
 #endif
@@ -718,86 +784,79 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
     }
     wsync();
 
-    // ---------------- stage 3c: alpha, beta, W_r_c (rpf.cpp:444-487), every lane redundantly ----
-    double alpha[3], beta[kNFeat], wrc;
+    // ---------------- stage 3c: alpha, beta, W_r_c (rpf.cpp:444-487), lane-parallel -----------------
+    // lane k < 12 owns feature k, lane c < 3 also owns colour channel c; values meet through a scratch area in the
+    // (now dead) histogram buffer: Drf[12] | Drc,Dpc,Dfc [9] | alpha[3] | beta[12] | wrc | coef[17]
+    double *sT = reinterpret_cast<double *>(sHist);
+    double *sDrf = sT, *sD9 = sT + 12, *sAlpha = sT + 24, *sBeta = sT + 28, *sWrc = sT + 40, *sCoef = sT + 44;
     {
-        double Drf[kNFeat], Dpf[kNFeat], Dcf[kNFeat], Drc[3], Dpc[3], Dfc[3];
+        const int k = min(lane, kNFeat - 1), c = min(lane, 2);
+        const double Drf = 0.0 + sMI[k * 4 + 0] + sMI[k * 4 + 1]; // rpf.cpp:421
+        const double Dpf = 0.0 + sMI[k * 4 + 2] + sMI[k * 4 + 3]; // rpf.cpp:425
+        const double Dcf = 0.0 + sMI[52 + k] + sMI[68 + k] + sMI[84 + k]; // PAPER numerator: sum_c MI(c_c, f_k)
+        const int base = 48 + c * 16;
+        const double Drc = 0.0 + sMI[base + 0] + sMI[base + 1];   // rpf.cpp:432
+        const double Dpc = 0.0 + sMI[base + 2] + sMI[base + 3];   // rpf.cpp:436
+        double Dfc = 0.0;
 #pragma unroll
-        for (int i = 0; i < kNFeat; ++i) {
-            Drf[i] = 0.0 + sMI[i * 4 + 0] + sMI[i * 4 + 1]; // rpf.cpp:421
-            Dpf[i] = 0.0 + sMI[i * 4 + 2] + sMI[i * 4 + 3]; // rpf.cpp:425
-            Dcf[i] = 0.0;
-        }
+        for (int j = 0; j < kNFeat; ++j) Dfc += sMI[base + 4 + j]; // rpf.cpp:440
+        wsync(); // every lane has read its MI values; the scratch area may now be written
+        if (lane < kNFeat) sDrf[lane] = Drf;
+        if (lane < 3) { sD9[lane] = Drc; sD9[3 + lane] = Dpc; sD9[6 + lane] = Dfc; }
+        wsync();
+        double D_f_c = 0.0, D_r_c = 0.0, D_p_c = 0.0;             // rpf.cpp:449-456
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int base = 48 + c * 16;
-            Drc[c] = 0.0 + sMI[base + 0] + sMI[base + 1]; // rpf.cpp:432
-            Dpc[c] = 0.0 + sMI[base + 2] + sMI[base + 3]; // rpf.cpp:436
-            double f = 0.0;
-#pragma unroll
-            for (int j = 0; j < kNFeat; ++j) {
-                f += sMI[base + 4 + j];                   // rpf.cpp:440
-                Dcf[j] += sMI[base + 4 + j];
-            }
-            Dfc[c] = f;
-        }
-        double D_f_c = 0.0, D_r_c = 0.0, D_p_c = 0.0;     // rpf.cpp:449-456
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { D_f_c += Dfc[i]; D_r_c += Drc[i]; D_p_c += Dpc[i]; }
+        for (int i = 0; i < 3; ++i) { D_f_c += sD9[6 + i]; D_r_c += sD9[i]; D_p_c += sD9[3 + i]; }
         const double e = (p.policy == RPF_DEGEN_EPS) ? p.eps : 0.0;
         const double den = D_f_c + D_r_c + D_p_c + e;
         double wsum = 0.0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const double w = Drc[i] / (Drc[i] + Dpc[i] + e); // rpf.cpp:470
-            alpha[i] = 1 - w;                                // rpf.cpp:475
-            wsum += w;
+        for (int i = 0; i < 3; ++i) wsum += sD9[i] / (sD9[i] + sD9[3 + i] + e); // rpf.cpp:470, 485
+        const double wrc = wsum / 3;                                           // rpf.cpp:487
+        const double alpha_c = 1 - Drc / (Drc + Dpc + e);                      // rpf.cpp:470, 475
+        double num; // what rpf.cpp:464 reads as D_f_ck[k] (3-element array indexed to 11: SURVEY F3)
+        if (p.beta_map == RPF_BETA_PAPER) num = Dcf;
+        else if (p.beta_map == RPF_BETA_REF_GCC11_O2) num = k < 3 ? sD9[6 + c] : (k < 8 ? 0.0 : sDrf[max(k - 8, 0)]);
+        else num = k < 3 ? sD9[6 + c] : (k < 4 ? 0.0 : sDrf[max(k - 4, 0)]);
+        const double Wc = num / den;                       // rpf.cpp:464
+        const double Wr = Drf / (Drf + Dpf + e);           // rpf.cpp:465
+        const double beta_k = (1 - Wr) * Wc;               // rpf.cpp:479
+        if (lane < kNFeat) {
+            sBeta[lane] = beta_k;
+            if (p.dbg.beta) p.dbg.beta[pix * kNFeat + lane] = beta_k;
         }
-        wrc = wsum / 3;                                      // rpf.cpp:487
-#pragma unroll
-        for (int k = 0; k < kNFeat; ++k) {
-            double num; // what rpf.cpp:464 reads as D_f_ck[k] (3-element array indexed to 11: SURVEY F3)
-            if (p.beta_map == RPF_BETA_PAPER) num = Dcf[k];
-            else if (p.beta_map == RPF_BETA_REF_GCC11_O2) num = k < 3 ? Dfc[k < 3 ? k : 0] : (k < 8 ? 0.0 : Drf[k >= 8 ? k - 8 : 0]);
-            else num = k < 3 ? Dfc[k < 3 ? k : 0] : (k < 4 ? 0.0 : Drf[k >= 4 ? k - 4 : 0]);
-            const double Wc = num / den;                       // rpf.cpp:464
-            const double Wr = Drf[k] / (Drf[k] + Dpf[k] + e);  // rpf.cpp:465
-            beta[k] = (1 - Wr) * Wc;                           // rpf.cpp:479
+        if (lane < 3) {
+            sAlpha[lane] = alpha_c;
+            if (p.dbg.alpha) p.dbg.alpha[pix * 3 + lane] = alpha_c;
         }
         if (lane == 0) {
+            sWrc[0] = wrc;
             if (p.dbg.wrc) p.dbg.wrc[pix] = wrc;
-            if (p.dbg.alpha)
-                for (int i = 0; i < 3; ++i) p.dbg.alpha[pix * 3 + i] = alpha[i];
-            if (p.dbg.beta)
-                for (int i = 0; i < kNFeat; ++i) p.dbg.beta[pix * kNFeat + i] = beta[i];
         }
+        wsync();
     }
+    const double wrc = sWrc[0];
 
     // ---------------- stage 4: weights and blend (rpf.cpp:627-717) ------------------------------
     // exponent of w_ij folded over raw values:  sum_k coef_k (x_ik - x_jk)^2  with
     // coef_k = weight_k / (SD_k^2 * 2 sigma^2); a column with SD_k == 0 normalises to z == 0 for every
-    // sample (ops.h:48), so its term is weight_k * 0.
-    double coef[17];
+    // sample (ops.h:48), so its term is weight_k * 0.  coef_k live in LDS and are re-read per use.
     {
         const double sigma_c2 = p.seed * p.seed / (1 - wrc) / (1 - wrc); // rpf.cpp:662
         const double inv2sc = 1.0 / (2 * sigma_c2);
         const double inv2sp = 1.0 / (2 * (p.sigma_p * p.sigma_p));       // rpf.cpp:664,668
-        double wk[17];
-        wk[0] = 1.0; wk[1] = 1.0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) wk[2 + k] = alpha[k];
-#pragma unroll
-        for (int k = 0; k < kNFeat; ++k) wk[5 + k] = beta[k];
-#pragma unroll
-        for (int k = 0; k < 17; ++k) {
+        if (lane < 17) {
+            const int k = lane;
             const int col = k < 5 ? k : k + 2;
             const double sd = sStat[kNDim + col];
+            const double wkk = k < 2 ? 1.0 : (k < 5 ? sAlpha[max(k - 2, 0)] : sBeta[max(k - 5, 0)]);
             const double s2 = k < 2 ? inv2sp : inv2sc;
-            coef[k] = (sd == 0.0) ? (wk[k] * 0.0) * s2 : wk[k] / (sd * sd) * s2;
+            sCoef[k] = (sd == 0.0) ? (wkk * 0.0) * s2 : wkk / (sd * sd) * s2;
         }
+        wsync();
     }
-    // fast-weights set-up (dead LDS regions: pair sums -> M / 1/SD of the 17 weighted columns; bin ids -> own z rows)
-    double *sFastM = reinterpret_cast<double *>(sPairF);
+    // fast-weights set-up (dead LDS regions: x-min/x-max slots -> M and 1/SD of the 17 weighted columns; bin ids -> own z rows)
+    double *sFastM = sStat + 2 * kNDim;  // the x-min / x-max slots are dead after stage 3a
     double *sFastI = sFastM + 17;
     float *sFastZ = reinterpret_cast<float *>(sBinW);
     float coefz[17];
@@ -806,7 +865,7 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
         const double inv2sc = 1.0 / (2 * sigma_c2), inv2sp = 1.0 / (2 * (p.sigma_p * p.sigma_p));
 #pragma unroll
         for (int k = 0; k < 17; ++k) {
-            const double wkk = k < 2 ? 1.0 : (k < 5 ? alpha[k < 5 && k >= 2 ? k - 2 : 0] : beta[k >= 5 ? k - 5 : 0]);
+            const double wkk = k < 2 ? 1.0 : (k < 5 ? sAlpha[k >= 2 && k < 5 ? k - 2 : 0] : sBeta[k >= 5 ? k - 5 : 0]);
             coefz[k] = (float)(wkk * (k < 2 ? inv2sp : inv2sc));
         }
         wsync();
@@ -825,12 +884,16 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
         }
         wsync();
     }
+    double coef[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) coef[k] = sCoef[k];
     bool bad = false;
 #ifndef RPF_X_SKIP4
-    for (int i0 = 0; i0 < ((p.stage_mask & 8) ? S : 0); i0 += 8) {
-        double sw[8], s0[8], s1[8], s2[8];
+    constexpr int kOwnBlock = 4; // own samples weighted per sweep over the neighbourhood (register budget: 3 waves/SIMD)
+    for (int i0 = 0; i0 < ((p.stage_mask & 8) ? S : 0); i0 += kOwnBlock) {
+        double sw[kOwnBlock], s0[kOwnBlock], s1[kOwnBlock], s2[kOwnBlock];
 #pragma unroll
-        for (int ii = 0; ii < 8; ++ii) { sw[ii] = 0.0; s0[ii] = 0.0; s1[ii] = 0.0; s2[ii] = 0.0; }
+        for (int ii = 0; ii < kOwnBlock; ++ii) { sw[ii] = 0.0; s0[ii] = 0.0; s1[ii] = 0.0; s2[ii] = 0.0; }
         // raw values of the lane's next neighbourhood sample are gathered while the current one is weighted
         float pf[14];  // columns 0,1 (pFilm) and 7..18 (features)
         double pc[3];  // colours
@@ -843,12 +906,12 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
                 for (int k = 0; k < 3; ++k) pc[k] = p.col_in[(uint64_t)k * p.plane_stride + off];
             }
         };
-        fetch17(lane);
         if constexpr (!FAST) {
 #pragma unroll 1
         for (int kk = 0; kk < K; ++kk) {
             const int j = lane + kWave * kk;
             if (j >= n) break;
+            fetch17(j); // no register double-buffering here: three waves per SIMD cover the gather latency
             double xj[17]; // order: p0 p1 | c0 c1 c2 | f0..f11
             xj[0] = (double)pf[0]; xj[1] = (double)pf[1];
 #pragma unroll
@@ -856,11 +919,15 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
 #pragma unroll
             for (int k = 0; k < 12; ++k) xj[5 + k] = (double)pf[2 + k];
             fetch17(j + kWave);
+            // the own samples' values are re-read from LDS for every neighbourhood sample on purpose: hoisting the
+            // 4 x 17 loop-invariant doubles into registers (what LICM would do) costs 136 VGPRs and a wave per SIMD
+            int own_base = i0 * kNDim;
+            asm volatile("" : "+v"(own_base));
 #pragma unroll
-            for (int ii = 0; ii < 8; ++ii) {
+            for (int ii = 0; ii < kOwnBlock; ++ii) {
                 const int i = i0 + ii;
                 if (i < S) {
-                    const double *oi = sOwn + i * kNDim;
+                    const double *oi = sOwn + own_base + ii * kNDim;
                     double E = 0.0;
 #pragma unroll
                     for (int k = 0; k < 17; ++k) {
@@ -883,6 +950,7 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
             for (int kk = 0; kk < K; ++kk) {
                 const int j = lane + kWave * kk;
                 if (j >= n) break;
+                fetch17(j);
                 float zj[17];
                 double cj[3];
                 zj[0] = (float)(((double)pf[0] - sFastM[0]) * sFastI[0]);
@@ -891,9 +959,8 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
                 for (int k = 0; k < 3; ++k) { cj[k] = pc[k]; zj[2 + k] = (float)((pc[k] - sFastM[2 + k]) * sFastI[2 + k]); }
 #pragma unroll
                 for (int k = 0; k < 12; ++k) zj[5 + k] = (float)(((double)pf[2 + k] - sFastM[5 + k]) * sFastI[5 + k]);
-                fetch17(j + kWave);
 #pragma unroll
-                for (int ii = 0; ii < 8; ++ii) {
+                for (int ii = 0; ii < kOwnBlock; ++ii) {
                     const int i = i0 + ii;
                     if (i < S) {
                         const float *zi = sFastZ + i * 20; // rows padded to 20 floats: five 16-byte reads
@@ -918,23 +985,20 @@ __global__ __launch_bounds__(64) void filter_pixel_kernel(PassParams p, LdsLayou
                 }
             }
         }
-        // 32 wave sums by two transposed butterflies, gathered through LDS: [0..7] sum w, [8..15] r, [16..23] g, [24..31] b
+        // 16 wave sums by one transposed butterfly, gathered through LDS: [0..3] sum w, [4..7] r, [8..11] g, [12..15] b
         {
-            double ga[16], gb[16];
+            double ga[16];
 #pragma unroll
-            for (int ii = 0; ii < 8; ++ii) { ga[ii] = sw[ii]; ga[8 + ii] = s0[ii]; gb[ii] = s1[ii]; gb[8 + ii] = s2[ii]; }
-            const double ta = xl::reduce16<xl::OpSum>(ga, lane), tb = xl::reduce16<xl::OpSum>(gb, lane);
+            for (int ii = 0; ii < kOwnBlock; ++ii) { ga[ii] = sw[ii]; ga[4 + ii] = s0[ii]; ga[8 + ii] = s1[ii]; ga[12 + ii] = s2[ii]; }
+            const double ta = xl::reduce16<xl::OpSum>(ga, lane);
             wsync();
-            if ((lane & 3) == 0) {
-                sMI[xl::slot16(lane)] = ta;
-                sMI[16 + xl::slot16(lane)] = tb;
-            }
+            if ((lane & 3) == 0) sMI[xl::slot16(lane)] = ta;
             wsync();
-            if (lane < 24) {
+            if (lane < 3 * kOwnBlock) {
                 const int ii = lane / 3, k = lane % 3;
                 const int i = i0 + ii;
                 if (i < S) {
-                    double prime = sMI[8 * (k + 1) + ii] / sMI[ii];       // rpf.cpp:700
+                    double prime = sMI[4 * (k + 1) + ii] / sMI[ii];       // rpf.cpp:700
                     if (isnan(prime)) {                                    // rpf.cpp:702: the reference exits here
                         bad = true;
                         if (p.policy == RPF_DEGEN_EPS) prime = sOwn[i * kNDim + kColC + k];
@@ -1090,7 +1154,8 @@ int samples_per_lane(int nmax) {
 bool table_in_lds(int nmax) {
     const char *e = std::getenv("RPF_TABLE_IN_LDS"); // experiment knob
     if (e) return std::atoi(e) != 0 && (uint32_t)nmax * 8u <= 65536u;
-    return (uint32_t)nmax * 8u <= 8192u;
+    // K <= 8: the 3 KiB table is read through L1 instead, which is what lets 12 workgroups fit in 160 KiB of LDS
+    return samples_per_lane(nmax) > 8 && (uint32_t)nmax * 8u <= 8192u;
 }
 
 LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
@@ -1103,13 +1168,17 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     L.off_stat = o; o += align_up(4 * kNDim * 8, 16);
     L.off_hx = o; o += align_up(kNDim * 8, 16);
     L.off_pair = o; o += align_up(kNPair * 8, 16);
-    L.off_mi = o; o += align_up(kNPair * 8, 16);
+    L.off_mi = L.off_pair; // the MI values overwrite the pair sums in place
     L.off_own = o; o += align_up((uint32_t)S * kNDim * 8u, 16);
     L.off_off = o; o += align_up((uint32_t)nmax * 4u, 16);
     L.off_union = o;
-    const uint32_t stage = align_up(kNDim * (kStageChunk + 1) * 8, 16);
-    const uint32_t bins = align_up((uint32_t)kNDim * kWave * KW * 4u, 16);
-    o += bins > stage ? bins : stage;
+    const uint32_t stage = align_up(kNDim * (kStageHalf + 1) * 8, 16);
+    const uint32_t bins = K <= 8 ? align_up((uint32_t)kNDim * kWave * 5u, 16)          // 5-bit words + slot-6 bytes
+                                 : align_up((uint32_t)kNDim * kWave * KW * 4u, 16);     // bytes in KW words
+    uint32_t uni = bins > stage ? bins : stage;
+    const uint32_t fastz = align_up((uint32_t)S * 20u * 4u, 16);                         // fast-weights own z rows
+    if (fastz > uni) uni = fastz;
+    o += uni;
     L.off_hist = o;
     uint32_t cells = (uint32_t)bmax * (uint32_t)bmax;
     if (K <= 8 && cells < 512u) cells = 512u; // mi_stage clears with unconditional 1-KiB stores
