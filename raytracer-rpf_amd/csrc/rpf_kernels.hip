@@ -663,18 +663,19 @@ __global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLa
                 if (hf == 1) fetch(j0 + kStageChunk + lane); // next chunk's gathers overlap the serial chains below
                 if (chain && cnth > 0) {
                     const double *src = sStage + myc * (kStageHalf + 1);
-                    if (cnth == kStageHalf) { // full half: LDS reads issue 16 at a time, only the adds are serial
+                    if (cnth == kStageHalf) { // full half: LDS reads issue 8 at a time, only the adds are serial
 #pragma unroll
-                        for (int h = 0; h < kStageHalf; h += 16) {
-                            double v[16];
+                        for (int h = 0; h < kStageHalf; h += 8) {
+                            double v[8];
 #pragma unroll
-                            for (int q = 0; q < 16; ++q) v[q] = src[h + q];
+                            for (int q = 0; q < 8; ++q) v[q] = src[h + q];
                             if (is_sq) {
 #pragma unroll
-                                for (int q = 0; q < 16; ++q) v[q] = v[q] * v[q];    // ops.h:138 multiplyArrays
+                                for (int q = 0; q < 8; ++q) v[q] = v[q] * v[q];     // ops.h:138 multiplyArrays
                             }
 #pragma unroll
-                            for (int q = 0; q < 16; ++q) acc = acc + v[q];          // ops.h:121 / 138 sumArrays
+                            for (int q = 0; q < 8; ++q) acc = acc + v[q];           // ops.h:121 / 138 sumArrays
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     } else if (!is_sq) {
                         for (int q = 0; q < cnth; ++q) acc = acc + src[q];
