@@ -403,6 +403,163 @@ __device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist,
     for (int u = G; u < 4; ++u) acc4[u] = 0ull;
 }
 
+// Small neighbourhoods (KD <= 2 sample slots, i.e. N <= 128: the regime of real path-traced buffers, where most
+// pixels keep only their own S samples): a histogram costs a handful of LDS cycles, so the stage is latency bound.
+// This variant queues the atomics of up to 16 histograms back to back (one wave's LDS operations execute in
+// order, the clearing store sits between two histograms), then issues all D look-ups, then reduces the 16 sums
+// with one 16-slot butterfly: two round trips per 16 histograms instead of per 4.
+template <int KD, int KW, int ZN, int G, bool JOINT, bool PACK5>
+__device__ __forceinline__ void mi_group_deep(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, int lane,
+                                              const int (&cols)[16], const uint32_t (&akey)[KD], bool last_ok,
+                                              uint32_t hole, int cells, uint64_t (&acc)[16]) {
+    uint32_t old[G][KD];
+    const uint32_t one = 1u, last_inc = last_ok ? 1u : 0u;
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        BinIds<KW, PACK5> w;
+        load_bins<KD, KW, PACK5>(sBinW, cols[u], lane, w);
+#pragma unroll
+        for (int kk = 0; kk < KD; ++kk) {
+            uint32_t key = w.get(kk);
+            if (JOINT) key += akey[kk];                                      // mi.cpp:39
+            if (kk == KD - 1) key = last_ok ? key : hole;
+            old[u][kk] = atomicAdd(&sHist[key], kk == KD - 1 ? last_inc : one);
+        }
+        zero_cells<(JOINT ? ZN : (ZN > 0 ? 1 : 0))>(sHist, cells, lane);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        uint64_t a = 0ull;
+        if (u < G) {
+            uint64_t d[KD];
+#pragma unroll
+            for (int kk = 0; kk < KD; ++kk) d[kk] = dtab[old[u][kk]];
+            a = last_ok ? d[KD - 1] : 0ull;
+#pragma unroll
+            for (int kk = 0; kk < KD - 1; ++kk) a += d[kk];
+        }
+        acc[u] = a;
+    }
+}
+
+template <int KD, int KW, int ZN, bool PACK5>
+__device__ __forceinline__ void mi_stage_deep(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, uint64_t *sHXf,
+                                              uint64_t *sPairF, int lane, int n, int B) {
+    const int ncell2 = B * B;
+    const bool last_ok = (lane + kWave * (KD - 1)) < n;
+    const uint32_t hole1 = (uint32_t)min(lane, B - 1);
+    const uint32_t hole2 = (uint32_t)min(lane, ncell2 - 1);
+    zero_cells<ZN>(sHist, ncell2, lane);
+    uint32_t akey[KD];
+#pragma unroll
+    for (int kk = 0; kk < KD; ++kk) akey[kk] = 0u;
+    uint64_t acc[16];
+    { // marginals: columns 0..15, then 16..18
+        const int cols[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+        mi_group_deep<KD, KW, ZN, 16, false, PACK5>(sBinW, sHist, dtab, lane, cols, akey, last_ok, hole1, B, acc);
+        const uint64_t tot = xl::reduce16<xl::OpSum>(acc, lane);
+        if ((lane & 3) == 0) sHXf[xl::slot16(lane)] = tot;
+    }
+    {
+        const int cols[16] = {16, 17, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18};
+        mi_group_deep<KD, KW, ZN, 3, false, PACK5>(sBinW, sHist, dtab, lane, cols, akey, last_ok, hole1, B, acc);
+        const uint64_t tot = xl::reduce16<xl::OpSum>(acc, lane);
+        if ((lane & 3) == 0 && xl::slot16(lane) < 3) sHXf[16 + xl::slot16(lane)] = tot;
+    }
+#pragma unroll 1
+    for (int g = 0; g < 7; ++g) {
+        const int acol = g < 2 ? kColR + g : (g < 4 ? kColP + (g - 2) : kColC + (g - 4));
+        const int l = g < 2 ? g : 2 + (g - 2);
+        {
+            BinIds<KW, PACK5> w;
+            load_bins<KD, KW, PACK5>(sBinW, acol, lane, w);
+#pragma unroll
+            for (int kk = 0; kk < KD; ++kk) akey[kk] = w.get(kk) * (uint32_t)B;
+        }
+        auto pair_index = [&](int i) { return g < 4 ? (i < 12 ? i * 4 + l : 48 + (i - 12) * 16 + l) : 48 + (g - 4) * 16 + 4 + i; };
+        // partners f0..f11 then (anchors r,p only) c0..c2; the c-anchors repeat a column for the unused slots
+        const int cols[16] = {kColF, kColF + 1, kColF + 2, kColF + 3, kColF + 4, kColF + 5, kColF + 6, kColF + 7,
+                              kColF + 8, kColF + 9, kColF + 10, kColF + 11, kColC, kColC + 1, kColC + 2, kColC + 2};
+        const int np = g < 4 ? 15 : 12;
+        if (g < 4) mi_group_deep<KD, KW, ZN, 15, true, PACK5>(sBinW, sHist, dtab, lane, cols, akey, last_ok, hole2, ncell2, acc);
+        else mi_group_deep<KD, KW, ZN, 12, true, PACK5>(sBinW, sHist, dtab, lane, cols, akey, last_ok, hole2, ncell2, acc);
+        const uint64_t tot = xl::reduce16<xl::OpSum>(acc, lane);
+        const int i = xl::slot16(lane);
+        if ((lane & 3) == 0 && i < np) sPairF[pair_index(i)] = tot;
+    }
+}
+
+// Tiny neighbourhoods (one sample slot: N <= 64, B <= 8, at most 64 cells) -- what real path-traced buffers mostly
+// are (N = S for >90 % of pixels).  Returning atomics would serialise here: a dozen lanes hit the same
+// few cells.  Instead each 16-lane row increments its own replica of the histogram with a plain (non-returning)
+// atomic, lane c then reads the four replica counts of cell c with one 16-byte read, looks up T[count] and clears
+// the cell with one 16-byte store; two 256-word regions ping-pong so the atomics of histogram u+1 are queued before
+// histogram u is read.  Sixteen histograms share one 16-slot butterfly.  Layout of a region: [cell][replica].
+template <int G, bool JOINT, int KW, bool PACK5>
+__device__ __forceinline__ void mi_group_tiny(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *ttab, int lane,
+                                              const int (&cols)[16], uint32_t akey, bool ok, uint64_t (&acc)[16]) {
+    const uint32_t rep = (uint32_t)lane >> 4;
+#pragma unroll
+    for (int u = 0; u <= G; ++u) {
+        if (u < G) {
+            BinIds<KW, PACK5> w;
+            load_bins<1, KW, PACK5>(sBinW, cols[u], lane, w);
+            uint32_t key = w.get(0);
+            if (JOINT) key += akey;                                          // mi.cpp:39
+            if (ok) atomicAdd(&sHist[(u & 1) * 256 + key * 4 + rep], 1u);
+        }
+        if (u >= 1) {
+            uint32_t *cell = sHist + ((u - 1) & 1) * 256 + lane * 4;         // lane = cell id (64 cells per region)
+            const uint4 c4 = *reinterpret_cast<const uint4 *>(cell);
+            *reinterpret_cast<uint4 *>(cell) = make_uint4(0u, 0u, 0u, 0u);
+            acc[u - 1] = ttab[c4.x + c4.y + c4.z + c4.w];                    // T[J] of this lane's cell (T[0] = 0)
+        }
+    }
+#pragma unroll
+    for (int u = G; u < 16; ++u) acc[u] = 0ull;
+}
+
+template <int KW, bool PACK5>
+__device__ __forceinline__ void mi_stage_tiny(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *ttab, uint64_t *sHXf,
+                                              uint64_t *sPairF, int lane, int n, int B) {
+    const bool ok = lane < n;
+    *reinterpret_cast<uint4 *>(sHist + lane * 4) = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4 *>(sHist + 256 + lane * 4) = make_uint4(0u, 0u, 0u, 0u);
+    uint64_t acc[16];
+    {
+        const int cols[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+        mi_group_tiny<16, false, KW, PACK5>(sBinW, sHist, ttab, lane, cols, 0u, ok, acc);
+        const uint64_t tot = xl::reduce16<xl::OpSum>(acc, lane);
+        if ((lane & 3) == 0) sHXf[xl::slot16(lane)] = tot;
+    }
+    {
+        const int cols[16] = {16, 17, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18, 18};
+        mi_group_tiny<3, false, KW, PACK5>(sBinW, sHist, ttab, lane, cols, 0u, ok, acc);
+        const uint64_t tot = xl::reduce16<xl::OpSum>(acc, lane);
+        if ((lane & 3) == 0 && xl::slot16(lane) < 3) sHXf[16 + xl::slot16(lane)] = tot;
+    }
+#pragma unroll 1
+    for (int g = 0; g < 7; ++g) {
+        const int acol = g < 2 ? kColR + g : (g < 4 ? kColP + (g - 2) : kColC + (g - 4));
+        const int l = g < 2 ? g : 2 + (g - 2);
+        uint32_t akey;
+        {
+            BinIds<KW, PACK5> w;
+            load_bins<1, KW, PACK5>(sBinW, acol, lane, w);
+            akey = w.get(0) * (uint32_t)B;
+        }
+        auto pair_index = [&](int i) { return g < 4 ? (i < 12 ? i * 4 + l : 48 + (i - 12) * 16 + l) : 48 + (g - 4) * 16 + 4 + i; };
+        const int cols[16] = {kColF, kColF + 1, kColF + 2, kColF + 3, kColF + 4, kColF + 5, kColF + 6, kColF + 7,
+                              kColF + 8, kColF + 9, kColF + 10, kColF + 11, kColC, kColC + 1, kColC + 2, kColC + 2};
+        const int np = g < 4 ? 15 : 12;
+        if (g < 4) mi_group_tiny<15, true, KW, PACK5>(sBinW, sHist, ttab, lane, cols, akey, ok, acc);
+        else mi_group_tiny<12, true, KW, PACK5>(sBinW, sHist, ttab, lane, cols, akey, ok, acc);
+        const uint64_t tot = xl::reduce16<xl::OpSum>(acc, lane);
+        const int i = xl::slot16(lane);
+        if ((lane & 3) == 0 && i < np) sPairF[pair_index(i)] = tot;
+    }
+}
+
 template <int KD, int KW, int ZN, bool FULL, bool PACK5>
 __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, uint64_t *sHXf,
                                          uint64_t *sPairF, int lane, int n, int B) {
@@ -752,8 +909,10 @@ __global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLa
             // counted lgkmcnt waits
 #define RPF_MI_CASE(KD_)                                                                                     \
     if constexpr (K >= KD_) {                                                                                \
-        if (B * B > 256) mi_stage<KD_, KW, 2, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);                 \
-        else mi_stage<KD_, KW, 1, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);                             \
+        if constexpr (KD_ == 1) mi_stage_tiny<KW, PACK5>(sBinW, sHist, p.tfix, sHXf, sPairF, lane, n, B); /* B*B <= 64 */ \
+        else if constexpr (KD_ == 2) mi_stage_deep<KD_, KW, 1, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); /* B*B <= 121 */ \
+        else if (B * B > 256) mi_stage<KD_, KW, 2, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); \
+        else mi_stage<KD_, KW, 1, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);               \
     }
             switch (kdyn) {
             case 1: RPF_MI_CASE(1) break;
