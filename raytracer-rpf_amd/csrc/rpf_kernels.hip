@@ -826,13 +826,10 @@ __global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLa
                             double v[8];
 #pragma unroll
                             for (int q = 0; q < 8; ++q) v[q] = src[h + q];
-                            if (is_sq) {
 #pragma unroll
-                                for (int q = 0; q < 8; ++q) v[q] = v[q] * v[q];     // ops.h:138 multiplyArrays
-                            }
+                            for (int q = 0; q < 8; ++q) v[q] = is_sq ? v[q] * v[q] : v[q]; // ops.h:138 multiplyArrays (branch-free)
 #pragma unroll
                             for (int q = 0; q < 8; ++q) acc = acc + v[q];           // ops.h:121 / 138 sumArrays
-                            __builtin_amdgcn_sched_barrier(0);
                         }
                     } else if (!is_sq) {
                         for (int q = 0; q < cnth; ++q) acc = acc + src[q];
