@@ -194,13 +194,18 @@ __device__ __forceinline__ double udiv(double a, const UDiv &d) {
 // operations execute in order).  Histograms are processed four at a time: the atomics of histogram u+1 are
 // queued before the D look-ups of histogram u are consumed, and the four per-lane sums are reduced together by
 // one transposed butterfly (no LDS).  KD = number of occupied sample slots of this pixel (compile time).
-// ZN > 0: the buffer holds >= 256*ZN cells and ZN unconditional full-wave 16-byte stores clear it (no exec
-// masking, no branch: cells past the live histogram are scratch).  ZN == 0: generic loop (large neighbourhoods).
+// Clearing a histogram with unconditional full-wave stores (no exec masking, no branch; cells past the live histogram
+// are scratch; the buffer holds >= 512 cells whenever ZN > 0).  ZN selects the store set by histogram size:
+//   1: one 16-byte store per lane (256 cells)        3: + one 4-byte store  (320 cells: B <= 17)
+//   4: + one 8-byte store (384 cells: B <= 19)        2: + one 16-byte store (512 cells)
+//   0: generic loop (large neighbourhoods)
 template <int ZN>
 __device__ __forceinline__ void zero_cells(uint32_t *h, int cells, int lane) {
     if constexpr (ZN > 0) {
-#pragma unroll
-        for (int i = 0; i < ZN; ++i) *reinterpret_cast<uint4 *>(h + lane * 4 + 256 * i) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4 *>(h + lane * 4) = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (ZN == 2) *reinterpret_cast<uint4 *>(h + 256 + lane * 4) = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (ZN == 3) h[256 + lane] = 0u;
+        if constexpr (ZN == 4) *reinterpret_cast<uint2 *>(h + 256 + lane * 2) = make_uint2(0u, 0u);
     } else {
         for (int t = lane * 4; t < cells; t += kWave * 4) *reinterpret_cast<uint4 *>(h + t) = make_uint4(0u, 0u, 0u, 0u);
     }
@@ -820,16 +825,16 @@ __global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLa
                 if (hf == 1) fetch(j0 + kStageChunk + lane); // next chunk's gathers overlap the serial chains below
                 if (chain && cnth > 0) {
                     const double *src = sStage + myc * (kStageHalf + 1);
-                    if (cnth == kStageHalf) { // full half: LDS reads issue 8 at a time, only the adds are serial
+                    if (cnth == kStageHalf) { // full half: LDS reads issue 16 at a time, only the adds are serial
 #pragma unroll
-                        for (int h = 0; h < kStageHalf; h += 8) {
-                            double v[8];
+                        for (int h = 0; h < kStageHalf; h += 16) {
+                            double v[16];
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) v[q] = src[h + q];
+                            for (int q = 0; q < 16; ++q) v[q] = src[h + q];
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) v[q] = is_sq ? v[q] * v[q] : v[q]; // ops.h:138 multiplyArrays (branch-free)
+                            for (int q = 0; q < 16; ++q) v[q] = is_sq ? v[q] * v[q] : v[q]; // ops.h:138 multiplyArrays (branch-free)
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) acc = acc + v[q];           // ops.h:121 / 138 sumArrays
+                            for (int q = 0; q < 16; ++q) acc = acc + v[q];          // ops.h:121 / 138 sumArrays
                         }
                     } else if (!is_sq) {
                         for (int q = 0; q < cnth; ++q) acc = acc + src[q];
@@ -908,8 +913,10 @@ __global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLa
     if constexpr (K >= KD_) {                                                                                \
         if constexpr (KD_ == 1) mi_stage_tiny<KW, PACK5>(sBinW, sHist, p.tfix, sHXf, sPairF, lane, n, B); /* B*B <= 64 */ \
         else if constexpr (KD_ == 2) mi_stage_deep<KD_, KW, 1, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); /* B*B <= 121 */ \
-        else if (B * B > 256) mi_stage<KD_, KW, 2, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); \
-        else mi_stage<KD_, KW, 1, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);               \
+        else if (B * B <= 256) mi_stage<KD_, KW, 1, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); \
+        else if (B * B <= 320) mi_stage<KD_, KW, 3, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); \
+        else if (B * B <= 384) mi_stage<KD_, KW, 4, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); \
+        else mi_stage<KD_, KW, 2, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);               \
     }
             switch (kdyn) {
             case 1: RPF_MI_CASE(1) break;
