@@ -1002,31 +1002,20 @@ __global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLa
     const double wrc = sWrc[0];
 
     // ---------------- stage 4: weights and blend (rpf.cpp:627-717) ------------------------------
-    // exponent of w_ij folded over raw values:  sum_k coef_k (x_ik - x_jk)^2  with
-    // coef_k = weight_k / (SD_k^2 * 2 sigma^2); a column with SD_k == 0 normalises to z == 0 for every
-    // sample (ops.h:48), so its term is weight_k * 0.  coef_k live in LDS and are re-read per use.
-    {
-        const double sigma_c2 = p.seed * p.seed / (1 - wrc) / (1 - wrc); // rpf.cpp:662
-        const double inv2sc = 1.0 / (2 * sigma_c2);
-        const double inv2sp = 1.0 / (2 * (p.sigma_p * p.sigma_p));       // rpf.cpp:664,668
-        if (lane < 17) {
-            const int k = lane;
-            const int col = k < 5 ? k : k + 2;
-            const double sd = sStat[kNDim + col];
-            const double wkk = k < 2 ? 1.0 : (k < 5 ? sAlpha[max(k - 2, 0)] : sBeta[max(k - 5, 0)]);
-            const double s2 = k < 2 ? inv2sp : inv2sc;
-            sCoef[k] = (sd == 0.0) ? (wkk * 0.0) * s2 : wkk / (sd * sd) * s2;
-        }
-        wsync();
-    }
-    // fast-weights set-up (dead LDS regions: x-min/x-max slots -> M and 1/SD of the 17 weighted columns; bin ids -> own z rows)
+    // z-space set-up shared by both weight modes (dead LDS regions: x-min/x-max slots -> M and 1/SD of the 17 weighted
+    // columns; bin ids -> the own samples' rows).  With z = (x-M)/SD the exponent of w_ij is
+    //     sum_k cz_k (z_ik - z_jk)^2 = A_i + B_j + sum_k u_ik z_jk,   cz_k = weight_k / (2 sigma^2),
+    //     A_i = sum_k cz_k z_ik^2,  B_j = sum_k cz_k z_jk^2,  u_ik = -2 cz_k z_ik :
+    // 17 FMAs per pair instead of 17 x (sub, mul, fma).  z is O(1) by construction, so the cancellation in
+    // A + B - 2 dot costs ~1e-15 * cz in E (cz <= ~1e5): far below what exp() resolves.
     double *sFastM = sStat + 2 * kNDim;  // the x-min / x-max slots are dead after stage 3a
     double *sFastI = sFastM + 17;
-    float *sFastZ = reinterpret_cast<float *>(sBinW);
+    float *sFastZ = reinterpret_cast<float *>(sBinW);   // FAST: own z rows, fp32 [S][20]
+    double *sOwnU = reinterpret_cast<double *>(sBinW);  // !FAST: own rows, fp64 [S][18] = u_i0..u_i16, A_i
     float coefz[17];
-    if constexpr (FAST) {
-        const double sigma_c2 = p.seed * p.seed / (1 - wrc) / (1 - wrc);
-        const double inv2sc = 1.0 / (2 * sigma_c2), inv2sp = 1.0 / (2 * (p.sigma_p * p.sigma_p));
+    {
+        const double sigma_c2 = p.seed * p.seed / (1 - wrc) / (1 - wrc);     // rpf.cpp:662
+        const double inv2sc = 1.0 / (2 * sigma_c2), inv2sp = 1.0 / (2 * (p.sigma_p * p.sigma_p)); // rpf.cpp:664,668
 #pragma unroll
         for (int k = 0; k < 17; ++k) {
             const double wkk = k < 2 ? 1.0 : (k < 5 ? sAlpha[k >= 2 && k < 5 ? k - 2 : 0] : sBeta[k >= 5 ? k - 5 : 0]);
@@ -1036,21 +1025,34 @@ __global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLa
         if (lane < 17) {
             const int col = lane < 5 ? lane : lane + 2;
             const double sd = sStat[kNDim + col];
+            const double wkk = lane < 2 ? 1.0 : (lane < 5 ? sAlpha[max(lane - 2, 0)] : sBeta[max(lane - 5, 0)]);
             sFastM[lane] = sStat[col];
             sFastI[lane] = (sd == 0.0) ? 0.0 : 1.0 / sd; // SD == 0 normalises to z == 0 (ops.h:48)
+            sCoef[lane] = wkk * (lane < 2 ? inv2sp : inv2sc); // cz_k (overwrites the raw-space coefficient slot)
         }
         wsync();
-        for (int t = lane; t < S * 20; t += kWave) {
-            const int i = t / 20, k = t - i * 20;
-            float z = 0.f;
-            if (k < 17) z = (float)((sOwn[i * kNDim + (k < 5 ? k : k + 2)] - sFastM[k]) * sFastI[k]);
-            sFastZ[t] = z;
+        if constexpr (FAST) {
+            for (int t = lane; t < S * 20; t += kWave) {
+                const int i = t / 20, k = t - i * 20;
+                float z = 0.f;
+                if (k < 17) z = (float)((sOwn[i * kNDim + (k < 5 ? k : k + 2)] - sFastM[k]) * sFastI[k]);
+                sFastZ[t] = z;
+            }
+        } else {
+            for (int i = lane; i < S; i += kWave) {
+                double A = 0.0;
+#pragma unroll
+                for (int k = 0; k < 17; ++k) {
+                    const double z = (sOwn[i * kNDim + (k < 5 ? k : k + 2)] - sFastM[k]) * sFastI[k];
+                    const double t = sCoef[k] * z;
+                    A = fma(t, z, A);
+                    sOwnU[i * 18 + k] = -2.0 * t;
+                }
+                sOwnU[i * 18 + 17] = A;
+            }
         }
         wsync();
     }
-    double coef[17];
-#pragma unroll
-    for (int k = 0; k < 17; ++k) coef[k] = sCoef[k];
     bool bad = false;
 #ifndef RPF_X_SKIP4
     constexpr int kOwnBlock = 4; // own samples weighted per sweep over the neighbourhood (register budget: 3 waves/SIMD)
@@ -1072,40 +1074,42 @@ __global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLa
         };
         if constexpr (!FAST) {
 #pragma unroll 1
-        for (int kk = 0; kk < K; ++kk) {
-            const int j = lane + kWave * kk;
-            if (j >= n) break;
-            fetch17(j); // no register double-buffering here: three waves per SIMD cover the gather latency
-            double xj[17]; // order: p0 p1 | c0 c1 c2 | f0..f11
-            xj[0] = (double)pf[0]; xj[1] = (double)pf[1];
+            for (int kk = 0; kk < K; ++kk) {
+                const int j = lane + kWave * kk;
+                if (j >= n) break;
+                fetch17(j); // no register double-buffering here: three waves per SIMD cover the gather latency
+                double zj[17], cj[3];
+                double Bj = 0.0;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) xj[2 + k] = pc[k];
+                for (int k = 0; k < 17; ++k) {
+                    const double xv = k < 2 ? (double)pf[k] : (k < 5 ? pc[k < 5 && k >= 2 ? k - 2 : 0] : (double)pf[k >= 5 ? k - 3 : 0]);
+                    const double z = (xv - sFastM[k]) * sFastI[k];
+                    zj[k] = z;
+                    Bj = fma(sCoef[k] * z, z, Bj);
+                }
 #pragma unroll
-            for (int k = 0; k < 12; ++k) xj[5 + k] = (double)pf[2 + k];
-            fetch17(j + kWave);
-            // the own samples' values are re-read from LDS for every neighbourhood sample on purpose: hoisting the
-            // 4 x 17 loop-invariant doubles into registers (what LICM would do) costs 136 VGPRs and a wave per SIMD
-            int own_base = i0 * kNDim;
-            asm volatile("" : "+v"(own_base));
+                for (int k = 0; k < 3; ++k) cj[k] = pc[k];
+                const int own_base = i0 * 18;
 #pragma unroll
-            for (int ii = 0; ii < kOwnBlock; ++ii) {
-                const int i = i0 + ii;
-                if (i < S) {
-                    const double *oi = sOwn + own_base + ii * kNDim;
-                    double E = 0.0;
+                for (int ii = 0; ii < kOwnBlock; ++ii) {
+                    const int i = i0 + ii;
+                    if (i < S) {
+                        // 18 doubles of the own row as nine 16-byte broadcast reads
+                        const double2 *ui2 = reinterpret_cast<const double2 *>(sOwnU + own_base + ii * 18);
+                        double ui[18];
 #pragma unroll
-                    for (int k = 0; k < 17; ++k) {
-                        const double d = oi[k < 5 ? k : k + 2] - xj[k];
-                        E = fma(d * d, coef[k], E);
+                        for (int q = 0; q < 9; ++q) { const double2 v = ui2[q]; ui[2 * q] = v.x; ui[2 * q + 1] = v.y; }
+                        double E = ui[17] + Bj;
+#pragma unroll
+                        for (int k = 0; k < 17; ++k) E = fma(ui[k], zj[k], E);
+                        const double w = exp(-E);               // rpf.cpp:667-670
+                        sw[ii] += w;                            // rpf.cpp:691
+                        s0[ii] = fma(w, cj[0], s0[ii]);         // rpf.cpp:692 (raw neighbourhood colours)
+                        s1[ii] = fma(w, cj[1], s1[ii]);
+                        s2[ii] = fma(w, cj[2], s2[ii]);
                     }
-                    const double w = exp(-E);               // rpf.cpp:667-670
-                    sw[ii] += w;                            // rpf.cpp:691
-                    s0[ii] = fma(w, xj[2], s0[ii]);         // rpf.cpp:692 (raw neighbourhood colours)
-                    s1[ii] = fma(w, xj[3], s1[ii]);
-                    s2[ii] = fma(w, xj[4], s2[ii]);
                 }
             }
-        }
         } else {
             // opt-in RPF_FLAG_FAST_WEIGHTS: per-pair arithmetic in fp32 on z-space values (x-M)/SD that are formed in
             // fp64 (so large world coordinates do not cancel in fp32), v_exp_f32, fp64 accumulation of the sums.
@@ -1340,7 +1344,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     const uint32_t bins = K <= 8 ? align_up((uint32_t)kNDim * kWave * 5u, 16)          // 5-bit words + slot-6 bytes
                                  : align_up((uint32_t)kNDim * kWave * KW * 4u, 16);     // bytes in KW words
     uint32_t uni = bins > stage ? bins : stage;
-    const uint32_t fastz = align_up((uint32_t)S * 20u * 4u, 16);                         // fast-weights own z rows
+    const uint32_t fastz = align_up((uint32_t)S * 18u * 8u, 16);                         // own rows of the weight stage
     if (fastz > uni) uni = fastz;
     o += uni;
     L.off_hist = o;
