@@ -1089,25 +1089,32 @@ __global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLa
                 }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) cj[k] = pc[k];
-                const int own_base = i0 * 18;
+                // straight-line over the kOwnBlock own samples (a missing one re-reads the last row and its weight is
+                // forced to 0) so their dependent chains interleave; the 17-term dot product runs as four partial sums
 #pragma unroll
                 for (int ii = 0; ii < kOwnBlock; ++ii) {
                     const int i = i0 + ii;
-                    if (i < S) {
-                        // 18 doubles of the own row as nine 16-byte broadcast reads
-                        const double2 *ui2 = reinterpret_cast<const double2 *>(sOwnU + own_base + ii * 18);
-                        double ui[18];
+                    const bool live = i < S; // wave-uniform
+                    const double2 *ui2 = reinterpret_cast<const double2 *>(sOwnU + min(i, S - 1) * 18);
+                    double ui[18]; // the own row as nine 16-byte broadcast reads
 #pragma unroll
-                        for (int q = 0; q < 9; ++q) { const double2 v = ui2[q]; ui[2 * q] = v.x; ui[2 * q + 1] = v.y; }
-                        double E = ui[17] + Bj;
+                    for (int q = 0; q < 9; ++q) { const double2 v = ui2[q]; ui[2 * q] = v.x; ui[2 * q + 1] = v.y; }
+                    double e0 = ui[17] + Bj, e1 = 0.0, e2 = 0.0, e3 = 0.0;
 #pragma unroll
-                        for (int k = 0; k < 17; ++k) E = fma(ui[k], zj[k], E);
-                        const double w = exp(-E);               // rpf.cpp:667-670
-                        sw[ii] += w;                            // rpf.cpp:691
-                        s0[ii] = fma(w, cj[0], s0[ii]);         // rpf.cpp:692 (raw neighbourhood colours)
-                        s1[ii] = fma(w, cj[1], s1[ii]);
-                        s2[ii] = fma(w, cj[2], s2[ii]);
+                    for (int k = 0; k < 16; k += 4) {
+                        e0 = fma(ui[k], zj[k], e0);
+                        e1 = fma(ui[k + 1], zj[k + 1], e1);
+                        e2 = fma(ui[k + 2], zj[k + 2], e2);
+                        e3 = fma(ui[k + 3], zj[k + 3], e3);
                     }
+                    e0 = fma(ui[16], zj[16], e0);
+                    const double E = (e0 + e1) + (e2 + e3);
+                    double w = exp(-E);                         // rpf.cpp:667-670
+                    w = live ? w : 0.0;
+                    sw[ii] += w;                                // rpf.cpp:691
+                    s0[ii] = fma(w, cj[0], s0[ii]);             // rpf.cpp:692 (raw neighbourhood colours)
+                    s1[ii] = fma(w, cj[1], s1[ii]);
+                    s2[ii] = fma(w, cj[2], s2[ii]);
                 }
             }
         } else {
