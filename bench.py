@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--box", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fast-weights", action="store_true", help="opt-in fp32 pair weights (RPF_FLAG_FAST_WEIGHTS)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
 
 
