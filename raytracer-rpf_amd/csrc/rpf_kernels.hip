@@ -8,19 +8,24 @@
 //   rpf.cpp:556-717 gather, normalise, ComputeCFWeights,
 //                   weights, blend   + mi.cpp:5-90          -> filter_pixel_kernel     (one wave64 / pixel)
 //   rpf.cpp:779-794 per-pixel reduction (box r=0.5)         -> reduce_kernel
+//   rpf.cpp:37-101  visualizeSF + vis.cpp:34-51             -> feature_mean_kernel, feature_normalise_kernel
 //
-// filter_pixel_kernel, one 64-lane workgroup (= one wavefront) per pixel, LDS-resident working set:
-//   1b  candidates of the box window are tested 64 at a time in the reference's visiting order (own
-//       samples, then x-major / y-minor neighbours); a ballot + prefix popcount appends the accepted
-//       samples' offsets to an LDS list, so list order == reference neighbourhood order.
-//   2   neighbourhood mean/std need the reference's sequential summation order to be bit-exact: chunks of
-//       32 samples x 19 columns are staged through LDS (coalesced gathers), then 38 lanes each run one
-//       in-order fp64 chain (19 sums, 19 sums of squares).
-//   3   per column: z=(x-M)/SD, wave min/max, bin id (u8) into LDS; 19 marginal + 96 joint histograms by
-//       LDS atomics; MI = (T[N] + sum T[J] - sum T[hx] - sum T[hy]) / N with T[k]=k ln k tabulated, which
-//       is mi.cpp:79-86 rewritten over integer counts (no log evaluated on the device).
-//   4   weights/blend for 8 own samples at a time over the lane-strided neighbourhood, fp64, wave
-//       shuffle reductions.
+// filter_pixel_kernel: one 64-lane workgroup (= one wavefront) per pixel, 12 resident per CU (157 VGPRs, 12 KiB
+// LDS), no inter-workgroup communication; DESIGN.md section 4 walks through the stages:
+//   1b  candidates of the box window are tested 64 at a time in the reference's visiting order with their gathers
+//       three steps ahead; ballot + prefix popcount append accepted offsets to an LDS list (list order ==
+//       reference neighbourhood order)
+//   2   in-order (reference-order) sum / sum-of-squares chains per column through an LDS staging buffer; the
+//       column min/max of x ride along
+//   3a  bins_stage: z = (x-M)/SD and t = (z-lo)/(hi-lo)*B by exact division with a hoisted reciprocal; bin ids
+//       packed 5 bits per sample in LDS
+//   3b  mi_stage / mi_stage_deep / mi_stage_tiny: 19 marginal + 96 joint histograms by LDS atomics; MI from a
+//       2^-44 fixed-point k ln k table (exact integer sums, no log on the device)
+//   3c  alpha, beta, W_r_c lane-parallel through an LDS scratch area
+//   4   pair weights in z-space (A_i + B_j + u_i . z_j), fp64 (or fp32 with RPF_FLAG_FAST_WEIGHTS), LDS-free
+//       transposed-butterfly reductions (rpf_xlane.h)
+// Profiling knobs (environment, read on the host): RPF_STAGE_MASK (skip stages; results wrong), RPF_LDS_PAD
+// (lower occupancy), RPF_TABLE_IN_LDS.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <cstdlib>
@@ -679,7 +684,6 @@ __global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLa
     const uint64_t HW = (uint64_t)H * W;
     const uint64_t pix = (uint64_t)y * W + x;
 
-    auto Dl = [&](uint32_t k) -> uint64_t { return T_IN_LDS ? sD[k] : p.dfix[k]; };
 
     if (T_IN_LDS)
         for (int k = lane; k < p.nmax; k += kWave) sD[k] = p.dfix[k];
@@ -902,7 +906,6 @@ __global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLa
         p.dbg.bin_hash[pix * kNDim + lane] = h;
     }
     // ---------------- stage 3b: histograms -> mutual information: mi_stage() above ------------
-#ifndef RPF_X_SKIPMI
     if (p.stage_mask & 4) {
         const uint64_t *dtab = T_IN_LDS ? sD : p.dfix;
         if constexpr (K <= 8) {
@@ -933,7 +936,6 @@ __global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLa
             mi_stage<K, KW, 0, false, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);
         }
     }
-#endif
     wsync();
     {
         const int64_t TNf = (int64_t)p.tfix[n];
@@ -1054,7 +1056,6 @@ __global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLa
         wsync();
     }
     bool bad = false;
-#ifndef RPF_X_SKIP4
     constexpr int kOwnBlock = 4; // own samples weighted per sweep over the neighbourhood (register budget: 3 waves/SIMD)
     for (int i0 = 0; i0 < ((p.stage_mask & 8) ? S : 0); i0 += kOwnBlock) {
         double sw[kOwnBlock], s0[kOwnBlock], s1[kOwnBlock], s2[kOwnBlock];
@@ -1183,7 +1184,6 @@ __global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLa
             }
         }
     }
-#endif
     if (__any(bad) && lane == 0) {
         atomicAdd(&p.status[0], 1);
         atomicMin(&p.status[1], (int)pix);

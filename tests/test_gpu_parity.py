@@ -174,6 +174,32 @@ def test_feature_images_bit_exact(ctx, hipmod, oracle):
     assert (got[0, ..., 0] == 0).all() and got[2].max() == 1.0
 
 
+@pytest.mark.parametrize("W,H,S,box", [(10, 8, 64, 7), (14, 10, 8, 9), (12, 9, 2, 7), (21, 6, 8, 7)])
+def test_more_shapes_vs_oracle(ctx, hipmod, oracle, W, H, S, box):
+    """the 49-samples-per-lane kernel (64 spp), a 9x9 box, 2 spp (B tiny: replicated-histogram path), a frame
+    whose width is not a multiple of anything"""
+    planes = fb.synth_planes(W, H, S, seed=23, sigma_f=0.02, sigma_c=0.01, mode="clustered")
+    got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS), box=box)
+    want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=box, policy=oracle.DEGEN_EPS))
+    check_pass(got, want, ab_rtol=1e-6)
+
+
+def test_small_neighbourhood_paths_vs_oracle(ctx, hipmod, oracle):
+    """N <= 64 (mi_stage_tiny) and 64 < N <= 128 (mi_stage_deep): tiny in-pixel jitter makes the 3-sigma test
+    reject most neighbours, the regime of real path-traced buffers"""
+    W, H, S = 30, 14, 8
+    seen_tiny = seen_deep = False
+    for sf in (1e-5, 2e-3, 8e-3):
+        planes = fb.synth_planes(W, H, S, seed=31, sigma_f=sf, sigma_c=0.01, mode="smooth")
+        got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS), box=7)
+        want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7, policy=oracle.DEGEN_EPS))
+        check_pass(got, want, ab_rtol=5e-3)
+        nb = want["nbhd_size"]
+        seen_tiny |= bool((nb <= 64).any())
+        seen_deep |= bool(((nb > 64) & (nb <= 128)).any())
+    assert seen_tiny and seen_deep
+
+
 def test_badarg_and_unsupported(ctx, hipmod):
     planes = np.zeros((19, 4, 4, 2), np.float32)
     with pytest.raises(hipmod.RpfError) as e:
