@@ -181,6 +181,15 @@ def main():
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "note": "the kernel is LDS-atomic/fp64-VALU bound (~350 ops/B, SURVEY 8d), not HBM bound"},
     }
+    # the pipe that actually bounds the fused kernel: LDS histogram atomics (19 marginal + 96 joint histograms per
+    # pixel, one increment per neighbourhood sample each).  Peak = measured ds_add_rtn_u32 rate on random cells
+    # (profiles/r01_lds_atomic_microbench.txt: 9.8 LDS cycles per 64 increments per CU at 8 waves/CU) x 256 CUs x 2.4 GHz.
+    incr = 115.0 * cnt.sum_nbhd
+    lds_peak = 256 * (64.0 / 9.8) * 2.4e9
+    out["lds_atomic_roofline"] = {"bound": "lds_atomics", "achieved": incr / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
+                                  "peak": lds_peak / 1e12, "unit": "T increments/s",
+                                  "frac": (incr / (k_ms * 1e-3)) / lds_peak if k_ms > 0 else 0.0,
+                                  "note": "whole-kernel time in the denominator; the MI stage alone is ~40% of it (scripts/ablate.sh)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(torch, planes, n_own, W, S, box, args.cpu_seconds, colour)
         if not args.fast_weights:
