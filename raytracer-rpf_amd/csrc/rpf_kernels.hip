@@ -217,43 +217,50 @@ __device__ __forceinline__ void zero_cells(uint32_t *h, int cells, int lane) {
 }
 
 // ---- bin-id storage of one pixel ---------------------------------------------------------------------------
-// PACK5 (kernels with K <= 8, where B = floor(sqrt(N)) <= 22): sample slots 0..5 of a lane are 5-bit fields of ONE
-// 32-bit word per (column, lane) -- [19][64] words -- and slot 6 is a byte in a side array [19][64] behind them:
-// 6 KiB per pixel instead of 9.5, which is what lets 12 single-wave workgroups share a CU's LDS.
-// Otherwise (large neighbourhoods): one byte per slot in KW words per (column, lane).
-template <int KW, bool PACK5>
+// PACK5 names the packing scheme (an int, historically a bool):
+//   1  kernels with K <= 8 (B = floor(sqrt(N)) <= 22): sample slots 0..5 of a lane are 5-bit fields of ONE 32-bit
+//      word per (column, lane) -- [19][64] words -- and slot 6 is a byte in a side array [19][64] behind them:
+//      6 KiB per pixel, which is what lets 12 single-wave workgroups share a CU's LDS
+//   5  K <= 17 (B <= 32): 5-bit fields, six per word, KW = ceil(K/6) words per (column, lane)
+//   6  larger K (B <= 64): 6-bit fields, five per word, KW = ceil(K/5) words per (column, lane)
+__host__ __device__ constexpr int pack_scheme(int K) { return K <= 8 ? 1 : (K <= 17 ? 5 : 6); }
+__host__ __device__ constexpr int pack_words(int K) { return K <= 8 ? 1 : (K <= 17 ? (K + 5) / 6 : (K + 4) / 5); }
+
+template <int KW, int PACK5>
 struct BinIds {
-    uint32_t w[PACK5 ? 1 : KW];
+    static constexpr int BITS = PACK5 == 6 ? 6 : 5;
+    static constexpr int SPW = 32 / BITS; // slots per word
+    uint32_t w[KW];
     uint32_t b6;
     __device__ __forceinline__ void clear() {
 #pragma unroll
-        for (int i = 0; i < (PACK5 ? 1 : KW); ++i) w[i] = 0u;
+        for (int i = 0; i < KW; ++i) w[i] = 0u;
         b6 = 0u;
     }
     __device__ __forceinline__ void set(int kk, uint32_t bin) { // kk is a compile-time constant at every call site
-        if constexpr (PACK5) {
+        if constexpr (PACK5 == 1) {
             if (kk < 6) w[0] |= bin << (5 * kk); else b6 = bin;
         } else {
-            w[kk >> 2] |= bin << (8 * (kk & 3));
+            w[kk / SPW] |= bin << (BITS * (kk % SPW));
         }
     }
     __device__ __forceinline__ uint32_t get(int kk) const {
-        if constexpr (PACK5) return kk < 6 ? ((w[0] >> (5 * kk)) & 31u) : b6;
-        else return (w[kk >> 2] >> (8 * (kk & 3))) & 0xffu;
+        if constexpr (PACK5 == 1) return kk < 6 ? ((w[0] >> (5 * kk)) & 31u) : b6;
+        else return (w[kk / SPW] >> (BITS * (kk % SPW))) & ((1u << BITS) - 1u);
     }
 };
-template <int KD, int KW, bool PACK5>
+template <int KD, int KW, int PACK5>
 __device__ __forceinline__ void store_bins(uint32_t *sBinW, int c, int lane, const BinIds<KW, PACK5> &b) {
-    if constexpr (PACK5) {
+    if constexpr (PACK5 == 1) {
         sBinW[c * kWave + lane] = b.w[0];
         if (KD > 6) reinterpret_cast<uint8_t *>(sBinW + kNDim * kWave)[c * kWave + lane] = (uint8_t)b.b6;
     } else {
         store_words<KW>(sBinW + ((size_t)c * kWave + lane) * KW, b.w);
     }
 }
-template <int KD, int KW, bool PACK5>
+template <int KD, int KW, int PACK5>
 __device__ __forceinline__ void load_bins(const uint32_t *sBinW, int c, int lane, BinIds<KW, PACK5> &b) {
-    if constexpr (PACK5) {
+    if constexpr (PACK5 == 1) {
         b.w[0] = sBinW[c * kWave + lane];
         b.b6 = (KD > 6) ? (uint32_t) reinterpret_cast<const uint8_t *>(sBinW + kNDim * kWave)[c * kWave + lane] : 0u;
     } else {
@@ -262,14 +269,15 @@ __device__ __forceinline__ void load_bins(const uint32_t *sBinW, int c, int lane
     }
 }
 // bin id of sample j = lane + 64*slot (debug hash only)
-template <int KW, bool PACK5>
+template <int KW, int PACK5>
 __device__ __forceinline__ uint32_t bin_of_sample(const uint32_t *sBinW, int c, int j) {
     const int ln = j & 63, slot = j >> 6;
-    if constexpr (PACK5) {
+    if constexpr (PACK5 == 1) {
         if (slot < 6) return (sBinW[c * kWave + ln] >> (5 * slot)) & 31u;
         return reinterpret_cast<const uint8_t *>(sBinW + kNDim * kWave)[c * kWave + ln];
     } else {
-        return reinterpret_cast<const uint8_t *>(sBinW + ((size_t)c * kWave + ln) * KW)[slot];
+        constexpr int BITS = PACK5 == 6 ? 6 : 5, SPW = 32 / BITS;
+        return (sBinW[((size_t)c * kWave + ln) * KW + slot / SPW] >> (BITS * (slot % SPW))) & ((1u << BITS) - 1u);
     }
 }
 
@@ -277,7 +285,7 @@ __device__ __forceinline__ uint32_t bin_of_sample(const uint32_t *sBinW, int c, 
 // bin ids are bytes packed per lane: sample kk of the lane is byte kk of KW words per column, written to LDS
 // [column][lane][KW] over the (now dead) staging buffer of stage 2.  KD = sample slots handled (the occupied
 // ones when the kernel is specialised on them, else K); holes compute on a dummy value and are masked.
-template <int KD, int KW, bool PACK5>
+template <int KD, int KW, int PACK5>
 __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sStat, const uint32_t *sOff, uint32_t *sBinW,
                                            int lane, int n, int B) {
     const double dB = (double)B;
@@ -334,7 +342,7 @@ __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sS
         };
         if (p.stage_mask & 2) {
             // the 16 fp32 columns (0,1,5..18) through kPF3 rotating register buffers, gathers kPF3 columns ahead
-            constexpr int kPF3 = 4;
+            constexpr int kPF3 = KD <= 8 ? 4 : (KD <= 13 ? 2 : 1); // register budget: KD floats per buffer
             float xb[kPF3][KD];
             auto colidx = [](int i) { return i < 2 ? i : i + 3; };
             auto issue3 = [&](int i, float (&dst)[KD]) {
@@ -373,7 +381,7 @@ __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sS
 // col0+u; for joints it bins (anchor, partner col(u)).  Slots kk < KD-1 are full by definition of KD (= ceil(n/64)),
 // so only the last slot carries the hole mask: `lastkey_ok` lanes exist, the others aim a +0 atomic at `hole`.
 // FULL = false (large neighbourhoods, KD = K): every slot carries its own mask (lane + 64*kk < n).
-template <int KD, int KW, int ZN, int G, bool JOINT, bool FULL, bool PACK5>
+template <int KD, int KW, int ZN, int G, bool JOINT, bool FULL, int PACK5>
 __device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, int lane, int n,
                                          const int (&cols)[4], const uint32_t (&akey)[KD], bool last_ok, uint32_t hole,
                                          int cells, uint64_t (&acc4)[4]) {
@@ -418,7 +426,7 @@ __device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist,
 // This variant queues the atomics of up to 16 histograms back to back (one wave's LDS operations execute in
 // order, the clearing store sits between two histograms), then issues all D look-ups, then reduces the 16 sums
 // with one 16-slot butterfly: two round trips per 16 histograms instead of per 4.
-template <int KD, int KW, int ZN, int G, bool JOINT, bool PACK5>
+template <int KD, int KW, int ZN, int G, bool JOINT, int PACK5>
 __device__ __forceinline__ void mi_group_deep(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, int lane,
                                               const int (&cols)[16], const uint32_t (&akey)[KD], bool last_ok,
                                               uint32_t hole, int cells, uint64_t (&acc)[16]) {
@@ -452,7 +460,7 @@ __device__ __forceinline__ void mi_group_deep(const uint32_t *sBinW, uint32_t *s
     }
 }
 
-template <int KD, int KW, int ZN, bool PACK5>
+template <int KD, int KW, int ZN, int PACK5>
 __device__ __forceinline__ void mi_stage_deep(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, uint64_t *sHXf,
                                               uint64_t *sPairF, int lane, int n, int B) {
     const int ncell2 = B * B;
@@ -505,7 +513,7 @@ __device__ __forceinline__ void mi_stage_deep(const uint32_t *sBinW, uint32_t *s
 // atomic, lane c then reads the four replica counts of cell c with one 16-byte read, looks up T[count] and clears
 // the cell with one 16-byte store; two 256-word regions ping-pong so the atomics of histogram u+1 are queued before
 // histogram u is read.  Sixteen histograms share one 16-slot butterfly.  Layout of a region: [cell][replica].
-template <int G, bool JOINT, int KW, bool PACK5>
+template <int G, bool JOINT, int KW, int PACK5>
 __device__ __forceinline__ void mi_group_tiny(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *ttab, int lane,
                                               const int (&cols)[16], uint32_t akey, bool ok, uint64_t (&acc)[16]) {
     const uint32_t rep = (uint32_t)lane >> 4;
@@ -529,7 +537,7 @@ __device__ __forceinline__ void mi_group_tiny(const uint32_t *sBinW, uint32_t *s
     for (int u = G; u < 16; ++u) acc[u] = 0ull;
 }
 
-template <int KW, bool PACK5>
+template <int KW, int PACK5>
 __device__ __forceinline__ void mi_stage_tiny(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *ttab, uint64_t *sHXf,
                                               uint64_t *sPairF, int lane, int n, int B) {
     const bool ok = lane < n;
@@ -570,7 +578,7 @@ __device__ __forceinline__ void mi_stage_tiny(const uint32_t *sBinW, uint32_t *s
     }
 }
 
-template <int KD, int KW, int ZN, bool FULL, bool PACK5>
+template <int KD, int KW, int ZN, bool FULL, int PACK5>
 __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, uint64_t *sHXf,
                                          uint64_t *sPairF, int lane, int n, int B) {
     const int ncell2 = B * B;
@@ -636,9 +644,9 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
 //   T_IN_LDS  keep the D table in LDS (small neighbourhoods) instead of reading it through L1
 // ------------------------------------------------------------------------------------------------
 template <int K, bool T_IN_LDS, bool FAST>
-__global__ __launch_bounds__(64, 3) void filter_pixel_kernel(PassParams p, LdsLayout L) {
-    constexpr int KW = (K + 3) / 4;          // 32-bit words of byte-packed bin ids per lane and column (K > 8)
-    constexpr bool PACK5 = (K <= 8);         // 5-bit packing, see BinIds
+__global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_pixel_kernel(PassParams p, LdsLayout L) {
+    constexpr int KW = pack_words(K);        // 32-bit words of packed bin ids per lane and column
+    constexpr int PACK5 = pack_scheme(K);    // packing scheme, see BinIds
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t *sD = reinterpret_cast<uint64_t *>(smem + L.off_T); // D[c] = T[c+1]-T[c], 2^-44 fixed point
     double *sStat = reinterpret_cast<double *>(smem + L.off_stat); // M[19], SD[19], xmin[19], xmax[19]
@@ -1327,16 +1335,16 @@ int samples_per_lane(int nmax) {
 }
 
 bool table_in_lds(int nmax) {
-    const char *e = std::getenv("RPF_TABLE_IN_LDS"); // experiment knob
-    if (e) return std::atoi(e) != 0 && (uint32_t)nmax * 8u <= 65536u;
-    // K <= 8: the 3 KiB table is read through L1 instead, which is what lets 12 workgroups fit in 160 KiB of LDS
-    return samples_per_lane(nmax) > 8 && (uint32_t)nmax * 8u <= 8192u;
+    // The D table is read through L1 (3 .. 25 KiB of LDS per workgroup buy resident waves, which is what these
+    // latency-bound kernels need); RPF_TABLE_IN_LDS=1 restores the LDS copy for experiments.
+    const char *e = std::getenv("RPF_TABLE_IN_LDS");
+    return e && std::atoi(e) != 0 && (uint32_t)nmax * 8u <= 65536u;
 }
 
 LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     LdsLayout L{};
     const int K = samples_per_lane(nmax);
-    const uint32_t KW = (uint32_t)(K + 3) / 4;
+    const uint32_t KW = (uint32_t)pack_words(K);
     uint32_t o = 0;
     L.off_T = o;
     if (t_in_lds) o += align_up((uint32_t)nmax * 8u, 16);
@@ -1349,7 +1357,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     L.off_union = o;
     const uint32_t stage = align_up(kNDim * (kStageHalf + 1) * 8, 16);
     const uint32_t bins = K <= 8 ? align_up((uint32_t)kNDim * kWave * 5u, 16)          // 5-bit words + slot-6 bytes
-                                 : align_up((uint32_t)kNDim * kWave * KW * 4u, 16);     // bytes in KW words
+                                 : align_up((uint32_t)kNDim * kWave * KW * 4u, 16);     // 5- or 6-bit fields in KW words
     uint32_t uni = bins > stage ? bins : stage;
     const uint32_t fastz = align_up((uint32_t)S * 18u * 8u, 16);                         // own rows of the weight stage
     if (fastz > uni) uni = fastz;
