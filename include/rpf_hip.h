@@ -66,10 +66,12 @@ typedef enum rpf_degenerate_policy {
 enum {
     RPF_FLAG_NONE = 0,
     RPF_FLAG_TIMING = 1,       /* bracket kernels with hipEvents (rpf_query_counters) */
-    RPF_FLAG_FAST_WEIGHTS = 2  /* opt-in: the S x N pair weights of stage 4 (rpf.cpp:637-678) are evaluated in fp32 on
+    RPF_FLAG_FAST_WEIGHTS = 2, /* opt-in: the S x N pair weights of stage 4 (rpf.cpp:637-678) are evaluated in fp32 on
                                   fp64-formed normalised values, with the hardware exp; everything that decides
                                   discrete outcomes (membership, bins, MI) is unchanged.  Colours move by ~1e-6
                                   relative (bar 1e-4).  Default off: fp64 throughout, like the reference. */
+    RPF_FLAG_NO_OVERLAP = 4    /* rpf_filter(): upload, filter and download one after the other instead of the
+                                  row-band pipeline (same results; for A/B timing).  RPF_FLAG_TIMING implies it. */
 };
 
 typedef struct rpf_desc {
@@ -132,6 +134,12 @@ const char *rpf_last_error(const rpf_ctx *ctx);
  */
 int32_t rpf_filter(rpf_ctx *ctx, const rpf_desc *desc, const float *planes, const float *ray_weight,
                    float *sample_rgb_out, float *pixel_rgb_out);
+
+/* Page-locked host memory for the buffers handed to rpf_filter(): a feature producer that writes its samples straight
+ * into such planes (instead of the reference's heap SamplingFilm, sample_film.cpp:6-43) gets full-rate DMA and real
+ * overlap of the upload with the first filter pass.  Pageable buffers work too, more slowly. */
+int32_t rpf_host_alloc(rpf_ctx *ctx, uint64_t bytes, void **out);
+int32_t rpf_host_free(rpf_ctx *ctx, void *ptr); /* ctx may be NULL */
 
 /* Same pass structure with every buffer already resident in HBM (device pointers).  d_colour is 3 fp64
  * planes [3][H][W][S], read as the input colours and overwritten with the filtered ones; planes 2..4 of

@@ -39,6 +39,9 @@ struct rpf_ctx {
     void *d_dbg[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_dbg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // host-buffer entry (rpf_filter): row-band pipeline, uploads / downloads on their own streams
+    hipStream_t s_up = nullptr, s_down = nullptr;
+    std::vector<hipEvent_t> band_ev; // no-timing events, two per band
     rpf_counters counters{};
 };
 
@@ -147,6 +150,8 @@ int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const float *d_plan
     return RPF_OK;
 }
 
+int32_t finish_counters(rpf_ctx *ctx, const rpf_desc *d, hipStream_t s);
+
 // runs all passes of desc on device-resident buffers; colour ends up in d_colour
 int32_t run_passes(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, double *d_colour, hipStream_t s) {
     const bool timing = (d->flags & RPF_FLAG_TIMING) != 0;
@@ -161,13 +166,17 @@ int32_t run_passes(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, doubl
     c.first_bad_pixel = -1;
     float ms_filter = 0.f, ms_stats = 0.f;
     if (timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
+    const size_t row = (size_t)d->W * d->S;
+    double *cin = d_colour, *cout = ctx->d_colB; // ping-pong: the filtered colours replace the film's (rpf.cpp:732)
     for (int i = 0; i < d->n_box; ++i) {
         PassSetup ps_;
-        if ((st = setup_pass(ctx, d, d->box_sizes[i], d_planes, d_colour, ctx->d_colB, nullptr, ps_))) return st;
+        if ((st = setup_pass(ctx, d, d->box_sizes[i], d_planes, cin, cout, nullptr, ps_))) return st;
         // rows outside the slab (halo) pass through unchanged
-        if (d->row_begin > 0 || d->row_end < d->H) HIP_TRY(launch_copy_f64(d_colour, ctx->d_colB, 3 * ps, s));
+        HIP_TRY(launch_copy_colour_span(cin, cout, ps, 0, (uint64_t)d->row_begin * row, s));
+        HIP_TRY(launch_copy_colour_span(cin, cout, ps, (uint64_t)d->row_end * row, (uint64_t)(d->H - d->row_end) * row, s));
         if (timing) HIP_TRY(hipEventRecord(ctx->ev[1], s));
-        HIP_TRY(launch_pixel_stats(ps_.p, s));
+        // stage 1a depends on the features only: formed once (the reference recomputes identical values per pass)
+        if (i == 0) HIP_TRY(launch_pixel_stats(ps_.p, s));
         if (timing) HIP_TRY(hipEventRecord(ctx->ev[2], s));
         HIP_TRY(launch_filter_pass(ps_.p, s, nullptr));
         if (timing) {
@@ -180,9 +189,9 @@ int32_t run_passes(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, doubl
             ms_filter += b;
         }
         c.filter_kernel_launches++;
-        // filtered colours replace the film's colours (rpf.cpp:732)
-        HIP_TRY(hipMemcpyAsync(d_colour, ctx->d_colB, 3 * ps * sizeof(double), hipMemcpyDeviceToDevice, s));
+        std::swap(cin, cout);
     }
+    if (cin != d_colour) HIP_TRY(hipMemcpyAsync(d_colour, cin, 3 * ps * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (timing) {
         HIP_TRY(hipEventRecord(ctx->ev[3], s));
         HIP_TRY(hipEventSynchronize(ctx->ev[3]));
@@ -190,6 +199,36 @@ int32_t run_passes(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, doubl
         HIP_TRY(hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[3]));
         c.device_total_ms = t;
     }
+    c.filter_kernel_ms = ms_filter;
+    c.stats_kernel_ms = ms_stats;
+    return finish_counters(ctx, d, s);
+}
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- host-buffer entry: row-band pipeline ----------------------------------------------------------------
+// rpf_filter() receives the film in host memory.  The planes are [dim][y][x][s], so a band of rows is one
+// contiguous span per plane: the image is cut into ~8 row bands, band j+1 is uploaded (s_up) while band j is
+// filtered (compute stream), and in the last pass band j is reduced and downloaded (s_down) while band j+1 is
+// filtered.  A band can be filtered once the b halo rows below it are resident, i.e. once the next band is up.
+// The per-pixel feature statistics (stage 1a) depend on the features only, so they are formed once, in pass 0
+// (the reference recomputes identical values every pass, rpf.cpp:529).
+struct Band { int r0, r1; };
+
+int32_t ensure_band_events(rpf_ctx *ctx, size_t n) {
+    while (ctx->band_ev.size() < n) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->band_ev.push_back(e);
+    }
+    return RPF_OK;
+}
+
+int32_t finish_counters(rpf_ctx *ctx, const rpf_desc *d, hipStream_t s) {
+    rpf_counters &c = ctx->counters;
     HIP_TRY(launch_nbhd_reduce(ctx->d_nbhd, d->W, d->row_begin, d->row_end, ctx->d_nred, s));
     int32_t hst[2];
     unsigned long long nred[2];
@@ -201,8 +240,6 @@ int32_t run_passes(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, doubl
     c.max_nbhd = (int32_t)nred[1];
     c.nonfinite_pixels = hst[0];
     c.first_bad_pixel = hst[0] ? hst[1] : -1;
-    c.filter_kernel_ms = ms_filter;
-    c.stats_kernel_ms = ms_stats;
     if (hst[0] && d->degenerate_policy == RPF_DEGEN_REF_ABORT) {
         char buf[160];
         std::snprintf(buf, sizeof(buf), "non-finite filtered colour at pixel (x=%d, y=%d); %d pixel(s) affected "
@@ -212,9 +249,115 @@ int32_t run_passes(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, doubl
     return RPF_OK;
 }
 
-double now_ms() {
-    using namespace std::chrono;
-    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+int32_t run_host_pipeline(rpf_ctx *ctx, const rpf_desc *d, const float *planes, const float *ray_weight,
+                          float *sample_rgb_out, float *pixel_rgb_out) {
+    const int W = d->W, H = d->H, S = d->S;
+    const size_t row = (size_t)W * S, ps = row * H;
+    hipStream_t s = ctx->stream, up = ctx->s_up, down = ctx->s_down;
+    int32_t st;
+    if ((st = ensure(ctx, ctx->d_colB, ctx->cap_colB, 3 * ps * sizeof(double)))) return st;
+
+    // bands: about eight, never thinner than the widest halo of the first / last pass (or 16 rows)
+    const int b_first = (d->box_sizes[0] - 1) / 2, b_last = (d->box_sizes[d->n_box - 1] - 1) / 2;
+    const int min_rows = std::max(16, std::max(b_first, b_last));
+    int nb = std::min(8, std::max(1, H / min_rows));
+    const int bh = (H + nb - 1) / nb;
+    nb = (H + bh - 1) / bh;
+    std::vector<Band> bands(nb);
+    for (int j = 0; j < nb; ++j) bands[j] = Band{j * bh, std::min(H, (j + 1) * bh)};
+    if ((st = ensure_band_events(ctx, 2 * (size_t)nb))) return st;
+    hipEvent_t *ev_up = ctx->band_ev.data(), *ev_done = ctx->band_ev.data() + nb;
+
+    const int32_t init_status[2] = {0, INT_MAX};
+    HIP_TRY(hipMemcpyAsync(ctx->d_status, init_status, sizeof(init_status), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(ctx->d_nred, 0, 2 * sizeof(unsigned long long), s));
+    rpf_counters &c = ctx->counters;
+    c = rpf_counters{};
+    c.first_bad_pixel = -1;
+
+    double *cin = ctx->d_colA, *cout = ctx->d_colB;
+    const bool want_out = sample_rgb_out || pixel_rgb_out;
+    const double t0 = now_ms();
+    for (int i = 0; i < d->n_box; ++i) {
+        const bool first = i == 0, last = i == d->n_box - 1;
+        PassSetup ps_;
+        if ((st = setup_pass(ctx, d, d->box_sizes[i], ctx->d_planes, cin, cout, nullptr, ps_))) return st;
+        // rows outside the slab pass through (rpf.cpp filters whole films; slabs are this build's multi-GPU cut)
+        auto pass_through = [&](int r0, int r1) -> hipError_t {
+            const int a0 = r0, a1 = std::min(r1, d->row_begin), b0 = std::max(r0, d->row_end), b1 = r1;
+            hipError_t e = hipSuccess;
+            if (a1 > a0) e = launch_copy_colour_span(cin, cout, ps, (uint64_t)a0 * row, (uint64_t)(a1 - a0) * row, s);
+            if (e == hipSuccess && b1 > b0)
+                e = launch_copy_colour_span(cin, cout, ps, (uint64_t)b0 * row, (uint64_t)(b1 - b0) * row, s);
+            return e;
+        };
+        auto filter_rows = [&](int r0, int r1) -> hipError_t {
+            PassParams q = ps_.p;
+            q.row_begin = std::max(r0, d->row_begin);
+            q.row_end = std::min(r1, d->row_end);
+            hipError_t e = pass_through(r0, r1);
+            if (e == hipSuccess && q.row_end > q.row_begin) {
+                e = launch_filter_pass(q, s, nullptr);
+                c.filter_kernel_launches++;
+            }
+            return e;
+        };
+        auto emit_rows = [&](int j) -> int32_t { // last pass: reduce + download band j
+            if (!want_out) return RPF_OK;
+            const Band &bd = bands[j];
+            HIP_TRY(launch_reduce_rows(cout, ray_weight ? ctx->d_rayw : nullptr, sample_rgb_out ? ctx->d_srgb : nullptr,
+                                       pixel_rgb_out ? ctx->d_prgb : nullptr, W, H, S, bd.r0, bd.r1, s));
+            HIP_TRY(hipEventRecord(ev_done[j], s));
+            HIP_TRY(hipStreamWaitEvent(down, ev_done[j], 0));
+            const size_t o = (size_t)bd.r0 * row, n = (size_t)(bd.r1 - bd.r0) * row;
+            if (sample_rgb_out)
+                for (int k = 0; k < 3; ++k)
+                    HIP_TRY(hipMemcpyAsync(sample_rgb_out + k * ps + o, ctx->d_srgb + k * ps + o, n * sizeof(float),
+                                           hipMemcpyDeviceToHost, down));
+            if (pixel_rgb_out)
+                HIP_TRY(hipMemcpyAsync(pixel_rgb_out + (size_t)bd.r0 * W * 3, ctx->d_prgb + (size_t)bd.r0 * W * 3,
+                                       (size_t)(bd.r1 - bd.r0) * W * 3 * sizeof(float), hipMemcpyDeviceToHost, down));
+            return RPF_OK;
+        };
+        if (!first && !last) { // middle passes: one launch over the slab
+            HIP_TRY(filter_rows(0, H));
+        } else {
+            for (int j = 0; j < nb; ++j) {
+                const Band &bd = bands[j];
+                if (first) {
+                    const size_t o = (size_t)bd.r0 * row, n = (size_t)(bd.r1 - bd.r0) * row;
+                    for (int k = 0; k < kNDim; ++k)
+                        HIP_TRY(hipMemcpyAsync(ctx->d_planes + k * ps + o, planes + k * ps + o, n * sizeof(float),
+                                               hipMemcpyHostToDevice, up));
+                    if (ray_weight)
+                        HIP_TRY(hipMemcpyAsync(ctx->d_rayw + o, ray_weight + o, n * sizeof(float), hipMemcpyHostToDevice, up));
+                    HIP_TRY(hipEventRecord(ev_up[j], up));
+                    HIP_TRY(hipStreamWaitEvent(s, ev_up[j], 0));
+                    HIP_TRY(launch_colour_from_planes_span(ctx->d_planes, cin, ps, o, n, s));
+                    HIP_TRY(launch_pixel_stats_rows(ps_.p, bd.r0, bd.r1, s));
+                    if (j >= 1) { // band j-1 has its lower halo now
+                        HIP_TRY(filter_rows(bands[j - 1].r0, bands[j - 1].r1));
+                        if (last && (st = emit_rows(j - 1))) return st;
+                    }
+                } else {
+                    HIP_TRY(filter_rows(bd.r0, bd.r1));
+                    if ((st = emit_rows(j))) return st;
+                }
+            }
+            if (first) {
+                HIP_TRY(filter_rows(bands[nb - 1].r0, bands[nb - 1].r1));
+                if (last && (st = emit_rows(nb - 1))) return st;
+            }
+        }
+        std::swap(cin, cout);
+    }
+    // cin now names the buffer holding the final colours; keep the convention "result in d_colA"
+    if (cin != ctx->d_colA) std::swap(ctx->d_colA, ctx->d_colB), std::swap(ctx->cap_colA, ctx->cap_colB);
+    const int32_t fst = finish_counters(ctx, d, s);
+    HIP_TRY(hipStreamSynchronize(down));
+    HIP_TRY(hipStreamSynchronize(up));
+    c.device_total_ms = (float)(now_ms() - t0); // wall clock of the overlapped upload + passes + download
+    return fst;
 }
 
 } // namespace
@@ -247,6 +390,8 @@ int32_t rpf_create(rpf_ctx **out, int32_t device) {
     *out = ctx; // returned even on failure so that rpf_last_error() can be read; caller destroys it
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->s_up, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->s_down, hipStreamNonBlocking));
     HIP_TRY(hipMalloc((void **)&ctx->d_status, 2 * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->d_nred, 2 * sizeof(unsigned long long)));
     for (auto &e : ctx->ev) HIP_TRY(hipEventCreate(&e));
@@ -265,7 +410,10 @@ void rpf_destroy(rpf_ctx *ctx) {
         if (b) (void)hipFree(b);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (auto &e : ctx->band_ev)
+        if (e) (void)hipEventDestroy(e);
+    for (hipStream_t q : {ctx->s_up, ctx->s_down, ctx->stream})
+        if (q) (void)hipStreamDestroy(q);
     delete ctx;
 }
 
@@ -312,6 +460,24 @@ int32_t rpf_filter_device(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes
     return run_passes(ctx, d, d_planes, d_colour, s);
 }
 
+int32_t rpf_host_alloc(rpf_ctx *ctx, uint64_t bytes, void **out) {
+    if (!ctx) return RPF_E_BADARG;
+    if (!out) return fail(ctx, RPF_E_BADARG, "out is NULL");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = hipHostMalloc(out, bytes ? (size_t)bytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess)
+        return fail(ctx, e == hipErrorOutOfMemory ? RPF_E_NOMEM : RPF_E_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    return RPF_OK;
+}
+
+int32_t rpf_host_free(rpf_ctx *ctx, void *ptr) { // ctx may be NULL (a buffer can outlive its context)
+    if (!ptr) return RPF_OK;
+    const hipError_t e = hipHostFree(ptr);
+    if (e != hipSuccess) return fail(ctx, RPF_E_HIP, std::string("hipHostFree: ") + hipGetErrorString(e));
+    return RPF_OK;
+}
+
 int32_t rpf_filter(rpf_ctx *ctx, const rpf_desc *d, const float *planes, const float *ray_weight,
                    float *sample_rgb_out, float *pixel_rgb_out) {
     int32_t st = validate(ctx, d, true);
@@ -325,6 +491,19 @@ int32_t rpf_filter(rpf_ctx *ctx, const rpf_desc *d, const float *planes, const f
     if (ray_weight && (st = ensure(ctx, ctx->d_rayw, ctx->cap_rayw, ps * sizeof(float)))) return st;
     if (sample_rgb_out && (st = ensure(ctx, ctx->d_srgb, ctx->cap_srgb, 3 * ps * sizeof(float)))) return st;
     if (pixel_rgb_out && (st = ensure(ctx, ctx->d_prgb, ctx->cap_prgb, 3 * HW * sizeof(float)))) return st;
+    // the band pipeline needs asynchronous copies, i.e. page-locked buffers on the host side (rpf_host_alloc or the
+    // caller's own hipHostMalloc / hipHostRegister); with pageable memory every copy blocks the submitting thread
+    // and the serial order is faster (scripts/host_path.py)
+    auto pinned = [](const void *p) {
+        if (!p) return true;
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeHost;
+    };
+    if (!(d->flags & (RPF_FLAG_TIMING | RPF_FLAG_NO_OVERLAP)) && pinned(planes) && pinned(ray_weight) &&
+        pinned(sample_rgb_out) && pinned(pixel_rgb_out))
+        return run_host_pipeline(ctx, d, planes, ray_weight, sample_rgb_out, pixel_rgb_out);
+    // serial variant (per-kernel event timing needs it): upload, passes, download
     const double t0 = now_ms();
     HIP_TRY(hipMemcpyAsync(ctx->d_planes, planes, kNDim * ps * sizeof(float), hipMemcpyHostToDevice, s));
     if (ray_weight) HIP_TRY(hipMemcpyAsync(ctx->d_rayw, ray_weight, ps * sizeof(float), hipMemcpyHostToDevice, s));

@@ -47,9 +47,16 @@ int samples_per_lane(int nmax); // the K the filter kernel is instantiated with 
 bool table_in_lds(int nmax);
 
 hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s);
+hipError_t launch_pixel_stats_rows(const PassParams &p, int r0, int r1, hipStream_t s);
 hipError_t launch_filter_pass(const PassParams &p, hipStream_t s, uint32_t *lds_bytes_out);
 hipError_t launch_colour_from_planes(const float *planes, double *colour, uint64_t plane_stride, hipStream_t s);
+hipError_t launch_colour_from_planes_span(const float *planes, double *colour, uint64_t plane_stride, uint64_t e0,
+                                          uint64_t cnt, hipStream_t s);
 hipError_t launch_copy_f64(const double *src, double *dst, uint64_t n, hipStream_t s);
+hipError_t launch_copy_colour_span(const double *src, double *dst, uint64_t plane_stride, uint64_t e0, uint64_t cnt,
+                                   hipStream_t s);
+hipError_t launch_reduce_rows(const double *colour, const float *ray_weight, float *sample_rgb, float *pixel_rgb, int W,
+                              int H, int S, int r0, int r1, hipStream_t s);
 hipError_t launch_reduce(const double *colour, const float *ray_weight, float *sample_rgb, float *pixel_rgb, int W,
                          int H, int S, hipStream_t s);
 hipError_t launch_nbhd_reduce(const int32_t *nbhd, int W, int row_begin, int row_end, unsigned long long *out2,

@@ -129,10 +129,10 @@ __device__ __forceinline__ double load_col(const PassParams &p, int c, uint32_t 
 // (rpf.cpp:338-347, ops.h:111-144).  Output planes [12][H*W] so the filter kernel reads them with
 // wave-uniform (scalar) loads.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pixel_stats_kernel(PassParams p) {
+__global__ __launch_bounds__(256) void pixel_stats_kernel(PassParams p, uint64_t pix0, uint64_t pix1) {
     const uint64_t HW = (uint64_t)p.H * p.W;
-    const uint64_t pix = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (pix >= HW) return;
+    const uint64_t pix = pix0 + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= pix1) return;
     const double dn = (double)p.S;
     for (int k = 0; k < kNFeat; ++k) {
         const float *src = p.planes + (uint64_t)(kColF + k) * p.plane_stride + pix * p.S;
@@ -1228,10 +1228,13 @@ __global__ __launch_bounds__(256) void udiv_selftest_kernel(uint64_t n, uint64_t
     if (bad) atomicAdd(mismatch, bad);
 }
 
-__global__ __launch_bounds__(256) void colour_from_planes_kernel(const float *planes, double *colour, uint64_t ps) {
+// elements [e0, e0+cnt) of each of the three colour planes
+__global__ __launch_bounds__(256) void colour_from_planes_kernel(const float *planes, double *colour, uint64_t ps,
+                                                                  uint64_t e0, uint64_t cnt) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= 3 * ps) return;
-    colour[i] = (double)planes[2 * ps + i];
+    if (i >= 3 * cnt) return;
+    const uint64_t c = i / cnt, e = e0 + (i - c * cnt);
+    colour[c * ps + e] = (double)planes[(2 + c) * ps + e];
 }
 
 __global__ __launch_bounds__(256) void copy_f64_kernel(const double *src, double *dst, uint64_t n) {
@@ -1239,12 +1242,21 @@ __global__ __launch_bounds__(256) void copy_f64_kernel(const double *src, double
     if (i < n) dst[i] = src[i];
 }
 
+__global__ __launch_bounds__(256) void copy_colour_span_kernel(const double *src, double *dst, uint64_t ps, uint64_t e0,
+                                                                uint64_t cnt) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 3 * cnt) return;
+    const uint64_t c = i / cnt, e = e0 + (i - c * cnt);
+    dst[c * ps + e] = src[c * ps + e];
+}
+
 // rpf.cpp:783-794 with the default box reconstruction filter: pixel = sum_s(L*rayWeight) / S
 __global__ __launch_bounds__(256) void reduce_kernel(const double *colour, const float *ray_weight, float *sample_rgb,
-                                                      float *pixel_rgb, int W, int H, int S) {
+                                                      float *pixel_rgb, int W, int H, int S, uint64_t pix0,
+                                                      uint64_t pix1) {
     const uint64_t HW = (uint64_t)H * W;
-    const uint64_t pix = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (pix >= HW) return;
+    const uint64_t pix = pix0 + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= pix1) return;
     const uint64_t ps = HW * S;
     for (int c = 0; c < 3; ++c) {
         double acc = 0.0;
@@ -1378,11 +1390,14 @@ hipError_t launch_udiv_selftest(uint64_t n, uint64_t seed, int mode, unsigned lo
     return hipGetLastError();
 }
 
-hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s) {
-    const uint64_t HW = (uint64_t)p.H * p.W;
-    hipLaunchKernelGGL(pixel_stats_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, s, p);
+hipError_t launch_pixel_stats_rows(const PassParams &p, int r0, int r1, hipStream_t s) {
+    if (r1 <= r0) return hipSuccess;
+    const uint64_t pix0 = (uint64_t)r0 * p.W, pix1 = (uint64_t)r1 * p.W;
+    hipLaunchKernelGGL(pixel_stats_kernel, dim3((unsigned)((pix1 - pix0 + 255) / 256)), dim3(256), 0, s, p, pix0, pix1);
     return hipGetLastError();
 }
+
+hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s) { return launch_pixel_stats_rows(p, 0, p.H, s); }
 
 hipError_t launch_filter_pass(const PassParams &p, hipStream_t s, uint32_t *lds_bytes_out) {
     const bool t_in_lds = table_in_lds(p.nmax);
@@ -1405,9 +1420,22 @@ hipError_t launch_filter_pass(const PassParams &p, hipStream_t s, uint32_t *lds_
     }
 }
 
+hipError_t launch_colour_from_planes_span(const float *planes, double *colour, uint64_t ps, uint64_t e0, uint64_t cnt,
+                                          hipStream_t s) {
+    if (cnt == 0) return hipSuccess;
+    hipLaunchKernelGGL(colour_from_planes_kernel, dim3((unsigned)((3 * cnt + 255) / 256)), dim3(256), 0, s, planes,
+                       colour, ps, e0, cnt);
+    return hipGetLastError();
+}
+
 hipError_t launch_colour_from_planes(const float *planes, double *colour, uint64_t ps, hipStream_t s) {
-    hipLaunchKernelGGL(colour_from_planes_kernel, dim3((unsigned)((3 * ps + 255) / 256)), dim3(256), 0, s, planes,
-                       colour, ps);
+    return launch_colour_from_planes_span(planes, colour, ps, 0, ps, s);
+}
+
+hipError_t launch_copy_colour_span(const double *src, double *dst, uint64_t ps, uint64_t e0, uint64_t cnt, hipStream_t s) {
+    if (cnt == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_colour_span_kernel, dim3((unsigned)((3 * cnt + 255) / 256)), dim3(256), 0, s, src, dst, ps,
+                       e0, cnt);
     return hipGetLastError();
 }
 
@@ -1416,12 +1444,18 @@ hipError_t launch_copy_f64(const double *src, double *dst, uint64_t n, hipStream
     return hipGetLastError();
 }
 
+hipError_t launch_reduce_rows(const double *colour, const float *ray_weight, float *sample_rgb, float *pixel_rgb, int W,
+                              int H, int S, int r0, int r1, hipStream_t s) {
+    if (r1 <= r0) return hipSuccess;
+    const uint64_t pix0 = (uint64_t)r0 * W, pix1 = (uint64_t)r1 * W;
+    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((pix1 - pix0 + 255) / 256)), dim3(256), 0, s, colour, ray_weight,
+                       sample_rgb, pixel_rgb, W, H, S, pix0, pix1);
+    return hipGetLastError();
+}
+
 hipError_t launch_reduce(const double *colour, const float *ray_weight, float *sample_rgb, float *pixel_rgb, int W,
                          int H, int S, hipStream_t s) {
-    const uint64_t HW = (uint64_t)H * W;
-    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, s, colour, ray_weight,
-                       sample_rgb, pixel_rgb, W, H, S);
-    return hipGetLastError();
+    return launch_reduce_rows(colour, ray_weight, sample_rgb, pixel_rgb, W, H, S, 0, H, s);
 }
 
 hipError_t launch_feature_images(const float *planes, int W, int H, int S, double *out, unsigned long long *maxbits, hipStream_t s) {

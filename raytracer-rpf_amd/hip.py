@@ -6,6 +6,7 @@ device pointers (e.g. torch tensors' ``data_ptr()``), torch is used by callers o
 streams and torch.distributed.
 """
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -19,10 +20,12 @@ BETA_REF_GCC11_O3, BETA_REF_GCC11_O2, BETA_PAPER = 0, 1, 2
 DEGEN_REF_ABORT, DEGEN_EPS = 0, 1
 FLAG_TIMING = 1
 FLAG_FAST_WEIGHTS = 2
+FLAG_NO_OVERLAP = 4
 
 EXPORTS = ["rpf_version", "rpf_status_string", "rpf_create", "rpf_destroy", "rpf_last_error", "rpf_filter",
            "rpf_filter_device", "rpf_colour_from_planes_device", "rpf_reduce_device", "rpf_stage_pixel_stats",
-           "rpf_filter_pass_debug", "rpf_query_counters", "rpf_lds_bytes_required", "rpf_selftest_udiv", "rpf_feature_images"]
+           "rpf_filter_pass_debug", "rpf_query_counters", "rpf_lds_bytes_required", "rpf_selftest_udiv", "rpf_feature_images",
+           "rpf_host_alloc", "rpf_host_free"]
 
 
 class Desc(C.Structure):
@@ -89,6 +92,8 @@ def load():
         L.rpf_feature_images.argtypes = [C.c_void_p, C.POINTER(Desc), C.c_void_p, C.c_void_p]
         L.rpf_lds_bytes_required.restype = C.c_int64
         L.rpf_lds_bytes_required.argtypes = [C.c_int32, C.c_int32]
+        L.rpf_host_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        L.rpf_host_free.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -153,12 +158,24 @@ class Context:
         return c
 
     # ---- host-buffer entry points ------------------------------------------------------------------
-    def filter(self, planes, desc, ray_weight=None, want_samples=True, want_pixels=True, allow_nonfinite=False):
+    def host_empty(self, shape, dtype=np.float32):
+        """numpy array in page-locked host memory (rpf_host_alloc); released when the last view of it is collected."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        ptr = C.c_void_p()
+        self._check(self._L.rpf_host_alloc(self._h, n, C.byref(ptr)))
+        buf = (C.c_char * max(n, 1)).from_address(ptr.value)
+        weakref.finalize(buf, self._L.rpf_host_free, None, ptr.value)  # released when the last view dies
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def filter(self, planes, desc, ray_weight=None, want_samples=True, want_pixels=True, allow_nonfinite=False,
+               out_samples=None, out_pixels=None):
         planes = np.ascontiguousarray(planes, np.float32)
         assert planes.shape == (NDIM, desc.H, desc.W, desc.S), planes.shape
         rw = None if ray_weight is None else np.ascontiguousarray(ray_weight, np.float32)
-        srgb = np.empty((3, desc.H, desc.W, desc.S), np.float32) if want_samples else None
-        prgb = np.empty((desc.H, desc.W, 3), np.float32) if want_pixels else None
+        srgb = out_samples if out_samples is not None else (
+            np.empty((3, desc.H, desc.W, desc.S), np.float32) if want_samples else None)
+        prgb = out_pixels if out_pixels is not None else (np.empty((desc.H, desc.W, 3), np.float32) if want_pixels else None)
         st = self._L.rpf_filter(self._h, C.byref(desc), _p(planes), _p(rw), _p(srgb), _p(prgb))
         self._check(st, allow=(E_NONFINITE,) if allow_nonfinite else ())
         return srgb, prgb, st

@@ -1,6 +1,7 @@
 // rpf_host.cpp -- see rpf_host.h.  Plain C++ (no HIP): everything device-side happens behind the C ABI.
 #include "rpf_host.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -17,6 +18,58 @@ RPFFilter::RPFFilter(int device) {
 
 RPFFilter::~RPFFilter() {
     if (ctx_) rpf_destroy(ctx_);
+}
+
+PlaneFilm::PlaneFilm(RPFFilter &owner, int width, int height, int spp, int x0, int y0)
+    : W_(width), H_(height), S_(spp), x0_(x0), y0_(y0) {
+    if (width <= 0 || height <= 0 || spp <= 0 || spp > 65535 || !owner.context()) return;
+    const size_t ps = (size_t)W_ * H_ * S_;
+    if (!planes_.resize(owner.context(), RPF_NDIM * ps) || !rayw_.resize(owner.context(), ps) ||
+        !srgb_.resize(owner.context(), 3 * ps)) {
+        planes_.release();
+        return;
+    }
+    count_.assign((size_t)W_ * H_, 0);
+}
+
+bool PlaneFilm::AddSample(int px, int py, const SampleData &s) {
+    const int x = px - x0_, y = py - y0_;
+    if (x < 0 || y < 0 || x >= W_ || y >= H_) return false;
+    const size_t pix = (size_t)y * W_ + x;
+    const int k = count_[pix];
+    if (k >= S_) return false;
+    const size_t ps = (size_t)W_ * H_ * S_, o = pix * S_ + k;
+    for (int d = 0; d < RPF_NDIM; ++d) planes_[(size_t)d * ps + o] = (float)s.data[d];
+    rayw_[o] = s.rayWeight;
+    count_[pix] = (uint16_t)(k + 1);
+    return true;
+}
+
+bool PlaneFilm::complete() const {
+    for (uint16_t c : count_)
+        if (c != S_) return false;
+    return !count_.empty();
+}
+
+int RPFFilter::FilterAndReduce(PlaneFilm &film, const std::vector<int> &boxes, std::vector<float> *pixel_rgb) {
+    if (!ctx_) return RPF_E_NODEVICE;
+    if (!film.ok()) { err_ = "PlaneFilm allocation failed"; return RPF_E_NOMEM; }
+    if (!film.complete()) { err_ = "PlaneFilm: some pixel holds fewer than S samples"; return RPF_E_BADARG; }
+    if (boxes.empty() || boxes.size() > RPF_MAX_BOXES) { err_ = "1..8 box sizes"; return RPF_E_BADARG; }
+    rpf_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.W = film.W_; d.H = film.H_; d.S = film.S_;
+    d.row_begin = 0; d.row_end = film.H_;
+    d.n_box = (int32_t)boxes.size();
+    for (size_t i = 0; i < boxes.size(); ++i) d.box_sizes[i] = boxes[i];
+    d.beta_map = beta_map; d.degenerate_policy = degenerate_policy;
+    d.eps = eps; d.sigma_seed = sigma_seed;
+    if (pixel_rgb) pixel_rgb->resize((size_t)film.W_ * film.H_ * 3);
+    const int32_t st = rpf_filter(ctx_, &d, film.planes_.data(), film.rayw_.data(), film.srgb_.data(),
+                                  pixel_rgb ? pixel_rgb->data() : nullptr);
+    rpf_query_counters(ctx_, &counters_);
+    if (st != RPF_OK) err_ = std::string(rpf_status_string(st)) + ": " + rpf_last_error(ctx_);
+    return st;
 }
 
 int RPFFilter::ApplyRPFFilter(SamplingFilm &film, const int /*tileSize*/, int box_size) {
@@ -48,9 +101,10 @@ int RPFFilter::run(SamplingFilm &film, const std::vector<int> &boxes, std::vecto
 
     // marshal AoS doubles [x][y][s][19] -> SoA fp32 planes [19][y][x][s] (values are fp32-valued: pbrt Float)
     const size_t ps = (size_t)W * H * S;
-    planes_.resize(RPF_NDIM * ps);
-    rayw_.resize(ps);
-    srgb_.resize(3 * ps);
+    if (!planes_.resize(ctx_, RPF_NDIM * ps) || !rayw_.resize(ctx_, ps) || !srgb_.resize(ctx_, 3 * ps)) {
+        err_ = "page-locked staging allocation failed";
+        return RPF_E_NOMEM;
+    }
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
@@ -70,7 +124,6 @@ int RPFFilter::run(SamplingFilm &film, const std::vector<int> &boxes, std::vecto
     for (size_t i = 0; i < boxes.size(); ++i) d.box_sizes[i] = boxes[i];
     d.beta_map = beta_map; d.degenerate_policy = degenerate_policy;
     d.eps = eps; d.sigma_seed = sigma_seed;
-    d.flags = RPF_FLAG_TIMING;
     if (pixel_rgb) pixel_rgb->resize((size_t)W * H * 3);
     const int32_t st = rpf_filter(ctx_, &d, planes_.data(), rayw_.data(), srgb_.data(), pixel_rgb ? pixel_rgb->data() : nullptr);
     rpf_query_counters(ctx_, &counters_);
@@ -123,5 +176,47 @@ extern "C" int32_t rpf_host_apply_filter_aos(double *aos, const float *ray_weigh
                 std::memcpy(aos + o * RPF_NDIM, film.samples[x][y][s].data, sizeof(double) * RPF_NDIM);
             }
     if (pixel_rgb_out) std::memcpy(pixel_rgb_out, pix.data(), pix.size() * sizeof(float));
+    return st;
+}
+
+extern "C" int32_t rpf_host_planefilm_filter(const double *aos, const float *ray_weight, int32_t W, int32_t H, int32_t S,
+                                             const int32_t *box_sizes, int32_t n_box, int32_t beta_map, int32_t policy,
+                                             int32_t device, float *sample_rgb_out, float *pixel_rgb_out, char *err,
+                                             int32_t err_len) {
+    using namespace rpf_host;
+    if (!aos || !box_sizes || W <= 0 || H <= 0 || S <= 0) return RPF_E_BADARG;
+    RPFFilter f(device);
+    f.beta_map = beta_map;
+    f.degenerate_policy = policy;
+    PlaneFilm film(f, W, H, S);
+    int st = RPF_OK;
+    if (!film.ok()) {
+        st = f.context() ? RPF_E_NOMEM : RPF_E_NODEVICE;
+    } else {
+        // 16x16 producer tiles, as RPFIntegrator::FillSampleFilm's ParallelFor2D hands them out (rpf.cpp:220-299)
+        const int tx = (W + 15) / 16, ty = (H + 15) / 16;
+        bool all = true;
+#pragma omp parallel for schedule(dynamic) reduction(&& : all)
+        for (int t = 0; t < tx * ty; ++t) {
+            const int x0 = (t % tx) * 16, y0 = (t / tx) * 16;
+            for (int y = y0; y < std::min(y0 + 16, (int)H); ++y)
+                for (int x = x0; x < std::min(x0 + 16, (int)W); ++x)
+                    for (int s = 0; s < S; ++s) {
+                        const size_t o = (((size_t)x * H + y) * S + s);
+                        SampleData sd;
+                        std::memcpy(sd.data, aos + o * RPF_NDIM, sizeof(double) * RPF_NDIM);
+                        sd.rayWeight = ray_weight ? ray_weight[o] : 1.0f;
+                        all = film.AddSample(x, y, sd) && all;
+                    }
+        }
+        std::vector<float> pix;
+        st = all ? f.FilterAndReduce(film, std::vector<int>(box_sizes, box_sizes + n_box), pixel_rgb_out ? &pix : nullptr)
+                 : (int)RPF_E_BADARG;
+        if (st == RPF_OK || st == RPF_E_NONFINITE) {
+            if (sample_rgb_out) std::memcpy(sample_rgb_out, film.filtered(), (size_t)3 * W * H * S * sizeof(float));
+            if (pixel_rgb_out) std::memcpy(pixel_rgb_out, pix.data(), pix.size() * sizeof(float));
+        }
+    }
+    if (err && err_len > 0) std::snprintf(err, err_len, "%s", f.last_error().c_str());
     return st;
 }

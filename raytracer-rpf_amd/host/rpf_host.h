@@ -40,6 +40,62 @@ struct SamplingFilm {
     void AddSample(int px, int py, const SampleData &s) { samples[px - x0][py - y0].push_back(s); } // sample_film.cpp:44
 };
 
+class RPFFilter;
+
+// Page-locked array handed out by the filter's context (rpf_host_alloc); grow-only, released with its owner.
+template <class T>
+class PinnedArray {
+  public:
+    PinnedArray() = default;
+    ~PinnedArray() { release(); }
+    PinnedArray(const PinnedArray &) = delete;
+    PinnedArray &operator=(const PinnedArray &) = delete;
+    bool resize(rpf_ctx *ctx, size_t n) { // contents are not preserved
+        if (n <= cap_) { n_ = n; return true; }
+        release();
+        void *p = nullptr;
+        if (rpf_host_alloc(ctx, (uint64_t)n * sizeof(T), &p) != RPF_OK) return false;
+        ptr_ = static_cast<T *>(p); cap_ = n_ = n;
+        return true;
+    }
+    void release() { if (ptr_) rpf_host_free(nullptr, ptr_); ptr_ = nullptr; cap_ = n_ = 0; }
+    T *data() { return ptr_; }
+    const T *data() const { return ptr_; }
+    size_t size() const { return n_; }
+    T &operator[](size_t i) { return ptr_[i]; }
+    const T &operator[](size_t i) const { return ptr_[i]; }
+  private:
+    T *ptr_ = nullptr;
+    size_t cap_ = 0, n_ = 0;
+};
+
+// the feature producer's film as SoA fp32 planes in page-locked memory, [19][y][x][s] -- what
+// FillSampleFilm / SamplingTile::addSample / MergeSamplingTile (rpf.cpp:220-299, sample_film.cpp:44-66) would fill
+// instead of the heap AoS-double SamplingFilm.  Every pixel holds exactly S samples (the filter's precondition).
+// AddSample needs no mutex: pbrt's render tiles are disjoint, so a pixel is only ever written by one thread.
+class PlaneFilm {
+  public:
+    PlaneFilm(RPFFilter &owner, int width, int height, int spp, int x0 = 0, int y0 = 0);
+    bool ok() const { return planes_.size() != 0; }
+    int getWidth() const { return W_; }
+    int getHeight() const { return H_; }
+    int samplesPerPixel() const { return S_; }
+    // appends to pixel (px,py); false if the pixel is outside the film or already holds S samples
+    bool AddSample(int px, int py, const SampleData &s);
+    bool complete() const; // every pixel has S samples
+    float *planes() { return planes_.data(); }          // [19][H][W][S]
+    float *rayWeight() { return rayw_.data(); }         // [H][W][S]
+    const float *filtered() const { return srgb_.data(); } // [3][H][W][S], valid after RPFFilter::FilterAndReduce
+    float filteredColor(int px, int py, int s, int c) const {
+        return srgb_[(size_t)c * W_ * H_ * S_ + ((size_t)(py - y0_) * W_ + (px - x0_)) * S_ + s];
+    }
+  private:
+    friend class RPFFilter;
+    int W_, H_, S_, x0_, y0_;
+    PinnedArray<float> planes_, rayw_, srgb_;
+    std::vector<uint16_t> count_;
+};
+
 class RPFFilter {
   public:
     explicit RPFFilter(int device = 0);
@@ -62,6 +118,10 @@ class RPFFilter {
     // The whole post-sampling part of Render(): every box size (rpf.cpp:767-775) and the film reduction with
     // the default box reconstruction filter (rpf.cpp:779-794): pixel_rgb[(y*W+x)*3+c], may be NULL.
     int FilterAndReduce(SamplingFilm &samplingFilm, const std::vector<int> &box_sizes, std::vector<float> *pixel_rgb);
+    // Same on a PlaneFilm: no marshalling at all, the pinned planes go straight to rpf_filter()'s band pipeline;
+    // filtered sample colours land in film.filtered().
+    int FilterAndReduce(PlaneFilm &film, const std::vector<int> &box_sizes, std::vector<float> *pixel_rgb);
+    rpf_ctx *context() { return ctx_; }
 
     const std::string &last_error() const { return err_; }
     const rpf_counters &counters() const { return counters_; }
@@ -71,7 +131,7 @@ class RPFFilter {
     rpf_ctx *ctx_ = nullptr;
     std::string err_;
     rpf_counters counters_{};
-    std::vector<float> planes_, rayw_, srgb_;
+    PinnedArray<float> planes_, rayw_, srgb_; // staging for the AoS film
 };
 
 } // namespace rpf_host
@@ -82,4 +142,9 @@ extern "C" {
 int32_t rpf_host_apply_filter_aos(double *aos, const float *ray_weight, int32_t W, int32_t H, int32_t S,
                                   const int32_t *box_sizes, int32_t n_box, int32_t beta_map, int32_t policy,
                                   int32_t device, float *pixel_rgb_out, char *err, int32_t err_len);
+// same input, but the samples are pushed into a PlaneFilm by concurrent 16x16-tile producers (as pbrt's render
+// tiles would); sample_rgb_out float [3][H][W][S], pixel_rgb_out float [H][W][3], either may be NULL.
+int32_t rpf_host_planefilm_filter(const double *aos, const float *ray_weight, int32_t W, int32_t H, int32_t S,
+                                  const int32_t *box_sizes, int32_t n_box, int32_t beta_map, int32_t policy,
+                                  int32_t device, float *sample_rgb_out, float *pixel_rgb_out, char *err, int32_t err_len);
 }

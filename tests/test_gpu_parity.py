@@ -148,6 +148,42 @@ def test_multi_pass_and_pixel_reduction(ctx, hipmod, oracle):
     assert cnt.samples_filtered == W * H * S * 2 and cnt.filter_kernel_launches == 2
 
 
+@pytest.mark.parametrize("boxes,rows", [((7,), None), ((7, 5), None), ((5, 7, 5), (6, 140)), ((7,), (20, 41))])
+def test_host_entry_band_pipeline_equals_serial(ctx, hipmod, oracle, boxes, rows):
+    """rpf_filter() on page-locked buffers (rpf_host_alloc) overlaps upload / filter / download over row bands; it
+    must give bit-for-bit what the serial sequence (RPF_FLAG_NO_OVERLAP, and any pageable buffer) gives"""
+    W, H, S = 40, 150, 8  # 150 rows -> eight bands of 19 rows
+    planes = fb.synth_planes(W, H, S, seed=21, sigma_f=1e-3, sigma_c=0.01, mode="clustered")
+    rw = (0.5 + np.random.default_rng(1).random((H, W, S))).astype(np.float32)
+    r0, r1 = rows if rows else (0, H)
+    kw = dict(boxes=boxes, row_begin=r0, row_end=r1, policy=hipmod.DEGEN_EPS)
+    s_ser, p_ser, st = ctx.filter(planes, hipmod.make_desc(W, H, S, flags=hipmod.FLAG_NO_OVERLAP, **kw), ray_weight=rw)
+    assert st == hipmod.OK
+    n_serial = ctx.counters().sum_nbhd
+    s_pipe, p_pipe, st = ctx.filter(planes, hipmod.make_desc(W, H, S, **kw), ray_weight=rw)
+    assert st == hipmod.OK
+    cnt = ctx.counters()
+    assert cnt.sum_nbhd == n_serial and cnt.samples_filtered == (r1 - r0) * W * S * len(boxes)
+    assert np.array_equal(s_pipe, s_ser) and np.array_equal(p_pipe, p_ser)
+    # page-locked producer-side buffers
+    pin = ctx.host_empty(planes.shape)
+    pin[...] = planes
+    pin_rw = ctx.host_empty(rw.shape)
+    pin_rw[...] = rw
+    out_s, out_p = ctx.host_empty(s_ser.shape), ctx.host_empty(p_ser.shape)
+    ctx.filter(pin, hipmod.make_desc(W, H, S, **kw), ray_weight=pin_rw, out_samples=out_s, out_pixels=out_p)
+    assert ctx.counters().filter_kernel_launches > len(boxes)  # the banded route ran (pageable buffers go serial)
+    assert np.array_equal(out_s, s_ser) and np.array_equal(out_p, p_ser)
+    s_pipe = out_s
+    # rows outside the slab come back unfiltered
+    if rows:
+        assert np.array_equal(s_pipe[:, :r0], planes[2:5, :r0]) and np.array_equal(s_pipe[:, r1:], planes[2:5, r1:])
+    # and the single-pass case against the oracle
+    if boxes == (7,) and rows is None:
+        want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7), debug=False)["colour"]
+        assert rel_l2(s_pipe.astype(np.float64), want) <= REL_L2_BAR
+
+
 def test_fast_weights_mode_meets_the_bar(ctx, hipmod, oracle):
     """RPF_FLAG_FAST_WEIGHTS: fp32 pair weights; every discrete outcome unchanged, colours within 1e-4 rel-L2"""
     for (W, H, S, mode, sf, sc) in [(24, 16, 8, "clustered", 1e-3, 0.01), (16, 12, 16, "clustered", 1e-3, 0.01),
@@ -247,6 +283,33 @@ def test_host_mirror_apply_rpf_filter(hipmod, oracle):
     keep = [0, 1] + list(range(5, 19))
     assert np.array_equal(aos[..., keep], before[..., keep])
     assert rel_l2(got, planes[2:5].astype(np.float64)) > 1e-3  # and the filter did something
+
+
+def test_host_plane_film_producer_equals_sampling_film(hipmod, oracle):
+    """concurrent tile producers AddSample() straight into page-locked SoA planes (PlaneFilm); the
+    filtered colours and pixel means equal what the AoS SamplingFilm route gives, bit for bit"""
+    lib = C.CDLL(os.path.join(os.path.dirname(hipmod.LIB_PATH), "librpf_host.so"))
+    W, H, S = 37, 45, 8
+    planes = fb.synth_planes(W, H, S, seed=8, sigma_f=1e-3, sigma_c=0.01, mode="clustered")
+    rw = (0.5 + np.random.default_rng(2).random((W, H, S))).astype(np.float32)  # SamplingFilm order [x][y][s]
+    aos = fb.planes_to_aos(planes)
+    boxes = (C.c_int32 * 2)(7, 5)
+    err = C.create_string_buffer(256)
+    srgb = np.empty((3, H, W, S), np.float32)
+    prgb = np.empty((H, W, 3), np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    st = lib.rpf_host_planefilm_filter(vp(aos), vp(rw), W, H, S, boxes, 2, 0, 1, 0, vp(srgb), vp(prgb), err, 256)
+    assert st == 0, err.value
+    aos2 = aos.copy()
+    prgb2 = np.empty((H, W, 3), np.float32)
+    st = lib.rpf_host_apply_filter_aos(vp(aos2), vp(rw), W, H, S, boxes, 2, 0, 1, 0, vp(prgb2), err, 256)
+    assert st == 0, err.value
+    got2 = np.transpose(aos2[..., 2:5], (3, 1, 0, 2)).astype(np.float32)
+    assert np.array_equal(srgb, got2) and np.array_equal(prgb, prgb2)
+    c = None
+    for box in (7, 5):
+        c = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=box, policy=1), colour_in=c, debug=False)["colour"]
+    assert rel_l2(srgb.astype(np.float64), c) <= REL_L2_BAR
 
 
 def test_full_size_1080p_properties(ctx, hipmod, oracle):
