@@ -41,10 +41,13 @@ struct PassParams {
 
 struct LdsLayout {
     uint32_t off_T, off_stat, off_hx, off_pair, off_mi, off_own, off_off, off_union, off_hist, total;
+    uint32_t hist_stride; // bytes of one wave's histogram buffer
+    uint32_t nw;          // waves per pixel (1 or 4)
 };
 LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds);
 int samples_per_lane(int nmax); // the K the filter kernel is instantiated with (0 = unsupported)
 bool table_in_lds(int nmax);
+int waves_per_pixel(int nmax);
 
 hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s);
 hipError_t launch_pixel_stats_rows(const PassParams &p, int r0, int r1, hipStream_t s);

@@ -285,9 +285,11 @@ __device__ __forceinline__ uint32_t bin_of_sample(const uint32_t *sBinW, int c, 
 // bin ids are bytes packed per lane: sample kk of the lane is byte kk of KW words per column, written to LDS
 // [column][lane][KW] over the (now dead) staging buffer of stage 2.  KD = sample slots handled (the occupied
 // ones when the kernel is specialised on them, else K); holes compute on a dummy value and are masked.
-template <int KD, int KW, int PACK5>
+// NW > 1 (several waves per pixel): the waves split the COLUMNS -- wave wv takes fp32 columns wv, wv+NW, ... of the
+// 16 and colour column wv -- and each still covers all n samples, so no bin word is shared between waves.
+template <int KD, int KW, int PACK5, int NW = 1>
 __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sStat, const uint32_t *sOff, uint32_t *sBinW,
-                                           int lane, int n, int B) {
+                                           int lane, int n, int B, int wv = 0) {
     const double dB = (double)B;
     {
         uint32_t offk[KD];
@@ -340,7 +342,34 @@ __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sS
             }
             store_bins<KD, KW, PACK5>(sBinW, c, lane, w);
         };
-        if (p.stage_mask & 2) {
+        if constexpr (NW > 1) {
+            if (p.stage_mask & 2) {
+                auto colidx = [](int i) { return i < 2 ? i : i + 3; };
+                float xb[KD];
+                auto issue3 = [&](int i) {
+                    const float *fplane = p.planes + (uint64_t)colidx(i) * p.plane_stride;
+#pragma unroll
+                    for (int kk = 0; kk < KD; ++kk) xb[kk] = fplane[offk[kk]];
+                };
+                issue3(wv); // NW <= 16
+#pragma unroll 1
+                for (int i = wv; i < 16; i += NW) {
+                    double xv[KD];
+#pragma unroll
+                    for (int kk = 0; kk < KD; ++kk) xv[kk] = (double)xb[kk];
+                    if (i + NW < 16) issue3(i + NW);
+                    do_column(colidx(i), xv);
+                }
+#pragma unroll 1
+                for (int c = wv; c < 3; c += NW) {
+                    double xc[KD];
+                    const double *dplane = p.col_in + (uint64_t)c * p.plane_stride;
+#pragma unroll
+                    for (int kk = 0; kk < KD; ++kk) xc[kk] = dplane[offk[kk]];
+                    do_column(kColC + c, xc);
+                }
+            }
+        } else if (p.stage_mask & 2) {
             // the 16 fp32 columns (0,1,5..18) through kPF3 rotating register buffers, gathers kPF3 columns ahead
             constexpr int kPF3 = KD <= 8 ? 4 : (KD <= 13 ? 2 : 1); // register budget: KD floats per buffer
             float xb[kPF3][KD];
@@ -578,9 +607,13 @@ __device__ __forceinline__ void mi_stage_tiny(const uint32_t *sBinW, uint32_t *s
     }
 }
 
-template <int KD, int KW, int ZN, bool FULL, int PACK5>
+// NW > 1: the 30 histogram groups (5 marginal + 25 joint) are dealt round-robin to the NW waves of the pixel; every
+// wave has its own histogram buffer and covers all n samples of its groups, so the stage needs no barrier.
+template <int KD, int KW, int ZN, bool FULL, int PACK5, int NW = 1>
 __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, uint64_t *sHXf,
-                                         uint64_t *sPairF, int lane, int n, int B) {
+                                         uint64_t *sPairF, int lane, int n, int B, int wv = 0) {
+    int gi = 0; // running group number (wave-uniform)
+    auto mine = [&]() { const bool m = (NW == 1) || (gi % NW) == wv; ++gi; return m; };
     const int ncell2 = B * B;
     const bool last_ok = (lane + kWave * (KD - 1)) < n;     // does this lane's last sample slot exist?
     const uint32_t hole1 = (uint32_t)min(lane, B - 1);      // harmless, spread-out targets of the +0 atomics
@@ -593,13 +626,14 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
     // ---- marginals: sum_i T[hx_i] per column; 19 columns = 4 groups of 4 + one group of 3
 #pragma unroll 1
     for (int c0 = 0; c0 < 16; c0 += 4) {
+        if (!mine()) continue;
         uint64_t acc4[4];
         const int cols[4] = {c0, c0 + 1, c0 + 2, c0 + 3};
         mi_group<KD, KW, ZN, 4, false, FULL, PACK5>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole1, B, acc4);
         const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
         if ((lane & 15) == 0) sHXf[c0 + xl::slot4(lane)] = tot;
     }
-    {
+    if (mine()) {
         uint64_t acc4[4];
         const int cols[4] = {16, 17, 18, 18};
         mi_group<KD, KW, ZN, 3, false, FULL, PACK5>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole1, B, acc4);
@@ -622,13 +656,14 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
         auto pair_index = [&](int i) { return g < 4 ? (i < 12 ? i * 4 + l : 48 + (i - 12) * 16 + l) : 48 + (g - 4) * 16 + 4 + i; };
 #pragma unroll 1
         for (int i0 = 0; i0 < 12; i0 += 4) { // partners f0..f11
+            if (!mine()) continue;
             uint64_t acc4[4];
             const int cols[4] = {kColF + i0, kColF + i0 + 1, kColF + i0 + 2, kColF + i0 + 3};
             mi_group<KD, KW, ZN, 4, true, FULL, PACK5>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole2, ncell2, acc4);
             const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
             if ((lane & 15) == 0) sPairF[pair_index(i0 + xl::slot4(lane))] = tot;
         }
-        if (g < 4) { // partners c0..c2 (wave-uniform branch)
+        if (g < 4 && mine()) { // partners c0..c2 (wave-uniform branch)
             uint64_t acc4[4];
             const int cols[4] = {kColC, kColC + 1, kColC + 2, kColC + 2};
             mi_group<KD, KW, ZN, 3, true, FULL, PACK5>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole2, ncell2, acc4);
@@ -643,8 +678,13 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
 //   K         compile-time bound on samples per lane: K*64 >= nmax ; lane owns samples j = lane + 64*kk
 //   T_IN_LDS  keep the D table in LDS (small neighbourhoods) instead of reading it through L1
 // ------------------------------------------------------------------------------------------------
-template <int K, bool T_IN_LDS, bool FAST>
-__global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_pixel_kernel(PassParams p, LdsLayout L) {
+//   NW        waves per pixel.  1: the workgroup is one wavefront (8 spp: twelve pixels in flight per CU).  4 (large
+//             neighbourhoods, whose 40-85 KiB of LDS would otherwise leave 1-3 waves on a CU): the waves of a pixel
+//             share the member list, the bin ids and the own rows, and split the work by COLUMN (stages 2, 3a), by
+//             HISTOGRAM GROUP (3b, one private histogram buffer per wave) and by OWN SAMPLE (4), so that every wave
+//             still walks all n samples in lane + 64*kk order and the stages need a barrier only where they meet.
+template <int K, bool T_IN_LDS, bool FAST, int NW>
+__global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 : (K <= 13 ? 2 : 1)))) void filter_pixel_kernel(PassParams p, LdsLayout L) {
     constexpr int KW = pack_words(K);        // 32-bit words of packed bin ids per lane and column
     constexpr int PACK5 = pack_scheme(K);    // packing scheme, see BinIds
     extern __shared__ __align__(16) unsigned char smem[];
@@ -657,9 +697,15 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
     uint32_t *sOff = reinterpret_cast<uint32_t *>(smem + L.off_off);
     double *sStage = reinterpret_cast<double *>(smem + L.off_union);    // [19][kStageHalf+1] (aliases bins)
     uint32_t *sBinW = reinterpret_cast<uint32_t *>(smem + L.off_union); // bin ids [19][64][KW] words (K > 8)
-    uint32_t *sHist = reinterpret_cast<uint32_t *>(smem + L.off_hist);
+    uint32_t *sHist0 = reinterpret_cast<uint32_t *>(smem + L.off_hist); // wave 0's histogram buffer (also scratch)
 
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = NW > 1 ? (tid & (kWave - 1)) : tid;
+    const int wv = NW > 1 ? (tid >> 6) : 0; // wave-uniform
+    uint32_t *sHist = reinterpret_cast<uint32_t *>(smem + L.off_hist + (NW > 1 ? (uint32_t)wv * L.hist_stride : 0u));
+    // hand-off between the waves of the pixel (s_barrier) -- or between the lanes of the only wave
+    auto bsync = [&]() { if constexpr (NW > 1) __syncthreads(); else wsync(); };
+    constexpr int kThreads = kWave * NW;
     const int W = p.W, H = p.H, S = p.S, b = p.b;
 
     // XCD- and L2-aware pixel assignment.  Blocks with equal (blockIdx % 8) share an XCD and its 4 MiB L2:
@@ -694,7 +740,7 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
 
 
     if (T_IN_LDS)
-        for (int k = lane; k < p.nmax; k += kWave) sD[k] = p.dfix[k];
+        for (int k = tid; k < p.nmax; k += kThreads) sD[k] = p.dfix[k];
 
     // ---------------- stage 1b: neighbourhood membership (rpf.cpp:556-586) ----------------------
     const int x0 = max(x - b, 0), x1 = min(x + b, W - 1);
@@ -704,10 +750,76 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
     const int centre_rank = (x - x0) * nyv + (y - y0);
     const int ncand = (ncells - 1) * S;
 
-    for (int s = lane; s < S; s += kWave) sOff[s] = (uint32_t)(pix * S + s); // own samples first
+    for (int s = tid; s < S; s += kThreads) sOff[s] = (uint32_t)(pix * S + s); // own samples first
 
     int n = S;
-    {
+    if constexpr (NW > 1) {
+        // Several waves: the 64-candidate blocks are dealt round-robin to the waves.  Pass A tests a wave's blocks and
+        // leaves one acceptance mask per block in LDS; pass B turns the masks into list positions (an exclusive scan
+        // over <= 64 block counts, done by every wave for itself) and appends, so the list order is the reference's.
+        uint64_t *sMask = reinterpret_cast<uint64_t *>(sHist0);
+        const int nblk = (ncand + kWave - 1) / kWave; // <= 64 (host-checked: nmax <= 4096)
+        double m12[kNFeat], lim12[kNFeat];
+#pragma unroll
+        for (int k = 0; k < kNFeat; ++k) {
+            m12[k] = p.pmean[(uint64_t)k * HW + pix];
+            lim12[k] = p.pstd[(uint64_t)k * HW + pix] * 3.0; // multiplyArray(std, 3), rpf.cpp:579
+        }
+        auto cand_off = [&](int qq) -> uint32_t {
+            int cell = qq / S;
+            const int s = qq - cell * S;
+            if (cell >= centre_rank) ++cell;          // rpf.cpp:565: skip the centre pixel
+            const int ix = cell / nyv;                 // xn outer ascending (rpf.cpp:562)
+            const int iy = cell - ix * nyv;            // yn inner ascending (rpf.cpp:563)
+            return (uint32_t)(((uint64_t)(y0 + iy) * W + (x0 + ix)) * S + s);
+        };
+        constexpr int kPF1 = 3;
+        float fb[kPF1][kNFeat];
+        auto issue1 = [&](int blk, float (&f)[kNFeat]) {
+            const int qq = blk * kWave + lane;
+            if (blk < nblk && qq < ncand) {
+                const uint32_t off = cand_off(qq);
+#pragma unroll
+                for (int k = 0; k < kNFeat; ++k) f[k] = p.planes[(uint64_t)(kColF + k) * p.plane_stride + off];
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < kPF1; ++u) issue1(wv + NW * u, fb[u]);
+#pragma unroll 1
+        for (int t0 = 0; wv + NW * t0 < nblk; t0 += kPF1) {
+#pragma unroll
+            for (int u = 0; u < kPF1; ++u) {
+                const int blk = wv + NW * (t0 + u);
+                if (blk < nblk) { // wave-uniform
+                    bool pass = (blk * kWave + lane) < ncand;
+#pragma unroll
+                    for (int k = 0; k < kNFeat; ++k) {
+                        const double a = fabs((double)fb[u][k] - m12[k]);
+                        if (a >= lim12[k]) pass = false;       // allLessThan: fails iff a >= b (ops.h:101-104)
+                    }
+                    const unsigned long long mask = __ballot(pass);
+                    if (lane == 0) sMask[blk] = mask;
+                    issue1(blk + NW * kPF1, fb[u]);
+                }
+            }
+        }
+        __syncthreads();
+        const int cnt = lane < nblk ? __popcll(sMask[lane]) : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int t = __shfl_up(incl, d, kWave);
+            if (lane >= d) incl += t;
+        }
+        const int excl = incl - cnt;
+#pragma unroll 1
+        for (int blk = wv; blk < nblk; blk += NW) {
+            const int base = S + __shfl(excl, blk, kWave);
+            const unsigned long long mask = sMask[blk];
+            if ((mask >> lane) & 1ull) sOff[base + __popcll(mask & ((1ull << lane) - 1ull))] = cand_off(blk * kWave + lane);
+        }
+        n = S + __shfl(incl, kWave - 1, kWave);
+    } else {
         double m12[kNFeat], lim12[kNFeat];
 #pragma unroll
         for (int k = 0; k < kNFeat; ++k) {
@@ -757,10 +869,10 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
             }
         }
     }
-    wsync();
-    if (lane == 0) p.nbhd[pix] = n;
+    bsync();
+    if (tid == 0) p.nbhd[pix] = n;
 
-    if (p.dbg.member_hash != nullptr && lane == 0) {
+    if (p.dbg.member_hash != nullptr && tid == 0) {
         uint32_t h = 2166136261u;
         for (int j = 0; j < n; ++j) {
             const uint32_t o = sOff[j];
@@ -778,116 +890,248 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
     // sum(x) chain of column `lane` and lanes 32..50 the sum(x*x) chain of column `lane-32`.
     // The per-column min / max of x ride along (order independent): z = (x-M)/SD is monotone in x, so
     // min z = z(min x) and max z = z(max x) exactly, which is all mi.cpp:47-50 needs.
-    float fmn[16], fmx[16];  // non-colour columns: 0,1 then 5..18
-    double cmn[3], cmx[3];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { fmn[i] = INFINITY; fmx[i] = -INFINITY; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { cmn[i] = INFINITY; cmx[i] = -INFINITY; }
-    {
-        double acc = 0.0;
-        const int myc = lane & 31;
-        const bool chain = myc < kNDim;
-        const bool is_sq = lane >= 32;
+    if constexpr (NW > 1) {
+        // Several waves: the in-order chains cannot be split (fp64 addition is not associative), so wave 0 does nothing
+        // but run them -- lanes 0..18 sum(x), lanes 32..50 sum(x*x), as in the one-wave path -- while waves 1..NW-1
+        // are producers: in round r producer w gathers the 19 values of the 64 samples of chunk r*(NW-1)+w-1 (issued
+        // one round ahead), tracks the column min / max and stages the chunk as doubles [column][65] in its own LDS
+        // buffer.  Barrier A: the buffers of the round are complete; wave 0 chains through them in order while the
+        // producers' next gathers are in flight; barrier B: the buffers may be overwritten.
+        constexpr int NP = NW - 1;
+        constexpr int kCS = kStageChunk + 1; // doubles per staged column
         const int nrun = (p.stage_mask & 1) ? n : 0;
-        float vf[16];
-        double vd[3];
-        auto fetch = [&](int j) {
-            if (j < nrun) {
-                const uint32_t off = sOff[j];
+        const int nround = (nrun + NP * kStageChunk - 1) / (NP * kStageChunk);
+        double *sMM = reinterpret_cast<double *>(sHist0); // [NP][38]: column min | max seen by each producer
+        if (wv == 0) {
+            double acc = 0.0;
+            const int myc = lane & 31;
+            const bool chain = myc < kNDim;
+            const bool is_sq = lane >= 32;
+            for (int r = 0; r < nround; ++r) {
+                __syncthreads(); // A
+#pragma unroll 1
+                for (int w = 0; w < NP; ++w) {
+                    const int cnt = min(kStageChunk, nrun - (r * NP + w) * kStageChunk); // wave-uniform
+                    if (cnt <= 0) break;
+                    if (chain) {
+                        const double *src = sStage + w * (kNDim * kCS) + myc * kCS;
+                        if (cnt == kStageChunk) { // LDS reads issue 16 at a time, only the adds are serial
 #pragma unroll
-                for (int i = 0; i < 16; ++i) vf[i] = p.planes[(uint64_t)(i < 2 ? i : i + 3) * p.plane_stride + off];
+                            for (int h = 0; h < kStageChunk; h += 16) {
+                                double v[16];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) vd[i] = p.col_in[(uint64_t)i * p.plane_stride + off];
-            }
-        };
-        fetch(lane);
-        for (int j0 = 0; j0 < nrun; j0 += kStageChunk) {
-            const int cnt = min(kStageChunk, nrun - j0);
-            if (lane < cnt) {
+                                for (int q = 0; q < 16; ++q) v[q] = src[h + q];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    fmn[i] = fminf(fmn[i], vf[i]);
-                    fmx[i] = fmaxf(fmx[i], vf[i]);
-                }
+                                for (int q = 0; q < 16; ++q) v[q] = is_sq ? v[q] * v[q] : v[q]; // ops.h:138 multiplyArrays
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    cmn[i] = fmin(cmn[i], vd[i]);
-                    cmx[i] = fmax(cmx[i], vd[i]);
-                }
-                if (j0 + lane < S) { // own samples are entries 0..S-1 of the neighbourhood
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) sOwn[(j0 + lane) * kNDim + (i < 2 ? i : i + 3)] = (double)vf[i];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) sOwn[(j0 + lane) * kNDim + kColC + i] = vd[i];
-                }
-            }
-            // the 64 gathered samples go through the LDS staging buffer 32 at a time ([19][33] doubles: 5 KiB)
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int cnth = min(kStageHalf, cnt - hf * kStageHalf); // wave-uniform, may be <= 0
-                const int t = lane - hf * kStageHalf;
-                if (t >= 0 && t < cnth) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) sStage[(i < 2 ? i : i + 3) * (kStageHalf + 1) + t] = (double)vf[i];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) sStage[(kColC + i) * (kStageHalf + 1) + t] = vd[i];
-                }
-                wsync();
-                if (hf == 1) fetch(j0 + kStageChunk + lane); // next chunk's gathers overlap the serial chains below
-                if (chain && cnth > 0) {
-                    const double *src = sStage + myc * (kStageHalf + 1);
-                    if (cnth == kStageHalf) { // full half: LDS reads issue 16 at a time, only the adds are serial
-#pragma unroll
-                        for (int h = 0; h < kStageHalf; h += 16) {
-                            double v[16];
-#pragma unroll
-                            for (int q = 0; q < 16; ++q) v[q] = src[h + q];
-#pragma unroll
-                            for (int q = 0; q < 16; ++q) v[q] = is_sq ? v[q] * v[q] : v[q]; // ops.h:138 multiplyArrays (branch-free)
-#pragma unroll
-                            for (int q = 0; q < 16; ++q) acc = acc + v[q];          // ops.h:121 / 138 sumArrays
+                                for (int q = 0; q < 16; ++q) acc = acc + v[q];                 // ops.h:121 / 138 sumArrays
+                            }
+                        } else if (!is_sq) {
+                            for (int q = 0; q < cnt; ++q) acc = acc + src[q];
+                        } else {
+                            for (int q = 0; q < cnt; ++q) { const double v = src[q]; acc = acc + v * v; }
                         }
-                    } else if (!is_sq) {
-                        for (int q = 0; q < cnth; ++q) acc = acc + src[q];
-                    } else {
-                        for (int q = 0; q < cnth; ++q) { const double v = src[q]; acc = acc + v * v; }
                     }
                 }
-                wsync();
+                __syncthreads(); // B
             }
-        }
-        const double sq = __shfl(acc, (lane & 31) + 32, 64);
-        const double dn = (double)n;
-        const double mean = acc / dn;                      // ops.h:123
-        double sd = sqrt(sq / dn - mean * mean);           // ops.h:141
-        if (p.policy == RPF_DEGEN_EPS && isnan(sd)) sd = 0.0;
-        if (lane < kNDim) {
-            sStat[lane] = mean;
-            sStat[kNDim + lane] = sd;
-            if (p.dbg.mean) p.dbg.mean[pix * kNDim + lane] = mean;
-            if (p.dbg.stddev) p.dbg.stddev[pix * kNDim + lane] = sd;
-        }
-        // wave min / max of x per column -> sStat[38 + c], sStat[57 + c]
-        {
+            const double sq = __shfl(acc, (lane & 31) + 32, 64);
+            const double dn = (double)n;
+            const double mean = acc / dn;                      // ops.h:123
+            double sd = sqrt(sq / dn - mean * mean);           // ops.h:141
+            if (p.policy == RPF_DEGEN_EPS && isnan(sd)) sd = 0.0;
+            if (lane < kNDim) {
+                sStat[lane] = mean;
+                sStat[kNDim + lane] = sd;
+                if (p.dbg.mean) p.dbg.mean[pix * kNDim + lane] = mean;
+                if (p.dbg.stddev) p.dbg.stddev[pix * kNDim + lane] = sd;
+            }
+        } else {
+            float fmn[16], fmx[16];  // non-colour columns: 0,1 then 5..18
+            double cmn[3], cmx[3];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { fmn[i] = INFINITY; fmx[i] = -INFINITY; }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { cmn[i] = INFINITY; cmx[i] = -INFINITY; }
+            double *sStageP = sStage + (wv - 1) * (kNDim * kCS);
+            float vf[16];
+            double vd[3];
+            auto fetch = [&](int j) {
+                if (j < nrun) {
+                    const uint32_t off = sOff[j];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) vf[i] = p.planes[(uint64_t)(i < 2 ? i : i + 3) * p.plane_stride + off];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) vd[i] = p.col_in[(uint64_t)i * p.plane_stride + off];
+                }
+            };
+            fetch((wv - 1) * kStageChunk + lane);
+            for (int r = 0; r < nround; ++r) {
+                const int j0 = (r * NP + wv - 1) * kStageChunk;
+                if (j0 + lane < nrun) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        fmn[i] = fminf(fmn[i], vf[i]);
+                        fmx[i] = fmaxf(fmx[i], vf[i]);
+                        sStageP[(i < 2 ? i : i + 3) * kCS + lane] = (double)vf[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        cmn[i] = fmin(cmn[i], vd[i]);
+                        cmx[i] = fmax(cmx[i], vd[i]);
+                        sStageP[(kColC + i) * kCS + lane] = vd[i];
+                    }
+                    if (j0 + lane < S) { // own samples are entries 0..S-1 of the neighbourhood
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) sOwn[(j0 + lane) * kNDim + (i < 2 ? i : i + 3)] = (double)vf[i];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) sOwn[(j0 + lane) * kNDim + kColC + i] = vd[i];
+                    }
+                }
+                __syncthreads(); // A
+                fetch(j0 + NP * kStageChunk + lane);
+                __syncthreads(); // B (also waits for the gathers just issued: wave 0 is chaining meanwhile)
+            }
+            // this wave's min / max of x per column -> sMM[wv-1][c], sMM[wv-1][19 + c]
+            double *mm = sMM + (wv - 1) * (2 * kNDim);
             float a32[32];
 #pragma unroll
             for (int i = 0; i < 16; ++i) { a32[i] = fmn[i]; a32[16 + i] = -fmx[i]; }
-            const float r = xl::reduce32<xl::OpMin>(a32, lane);
+            const float rr = xl::reduce32<xl::OpMin>(a32, lane);
             const int slot = xl::slot32(lane);
             if ((lane & 1) == 0) {
                 const int i = slot & 15;
                 const int col = i < 2 ? i : i + 3;
-                if (slot < 16) sStat[2 * kNDim + col] = (double)r;
-                else sStat[3 * kNDim + col] = (double)(-r);
+                if (slot < 16) mm[col] = (double)rr;
+                else mm[kNDim + col] = (double)(-rr);
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const double lo = xl::allreduce<xl::OpMin>(cmn[i]), hi = xl::allreduce<xl::OpMax>(cmx[i]);
-                if (lane == 0) { sStat[2 * kNDim + kColC + i] = lo; sStat[3 * kNDim + kColC + i] = hi; }
+                if (lane == 0) { mm[kColC + i] = lo; mm[kNDim + kColC + i] = hi; }
             }
         }
-        wsync();
+        __syncthreads();
+        if (tid < 2 * kNDim) { // min over the producers (slots 0..18), max (slots 19..37)
+            double v = sMM[tid];
+#pragma unroll
+            for (int w = 1; w < NP; ++w) v = tid < kNDim ? fmin(v, sMM[w * 2 * kNDim + tid]) : fmax(v, sMM[w * 2 * kNDim + tid]);
+            sStat[2 * kNDim + tid] = v;
+        }
+        __syncthreads();
+    } else {
+        float fmn[16], fmx[16];  // non-colour columns: 0,1 then 5..18
+        double cmn[3], cmx[3];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { fmn[i] = INFINITY; fmx[i] = -INFINITY; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { cmn[i] = INFINITY; cmx[i] = -INFINITY; }
+        {
+            double acc = 0.0;
+            const int myc = lane & 31;
+            const bool chain = myc < kNDim;
+            const bool is_sq = lane >= 32;
+            const int nrun = (p.stage_mask & 1) ? n : 0;
+            float vf[16];
+            double vd[3];
+            auto fetch = [&](int j) {
+                if (j < nrun) {
+                    const uint32_t off = sOff[j];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) vf[i] = p.planes[(uint64_t)(i < 2 ? i : i + 3) * p.plane_stride + off];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) vd[i] = p.col_in[(uint64_t)i * p.plane_stride + off];
+                }
+            };
+            fetch(lane);
+            for (int j0 = 0; j0 < nrun; j0 += kStageChunk) {
+                const int cnt = min(kStageChunk, nrun - j0);
+                if (lane < cnt) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        fmn[i] = fminf(fmn[i], vf[i]);
+                        fmx[i] = fmaxf(fmx[i], vf[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        cmn[i] = fmin(cmn[i], vd[i]);
+                        cmx[i] = fmax(cmx[i], vd[i]);
+                    }
+                    if (j0 + lane < S) { // own samples are entries 0..S-1 of the neighbourhood
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) sOwn[(j0 + lane) * kNDim + (i < 2 ? i : i + 3)] = (double)vf[i];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) sOwn[(j0 + lane) * kNDim + kColC + i] = vd[i];
+                    }
+                }
+                // the 64 gathered samples go through the LDS staging buffer 32 at a time ([19][33] doubles: 5 KiB)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int cnth = min(kStageHalf, cnt - hf * kStageHalf); // wave-uniform, may be <= 0
+                    const int t = lane - hf * kStageHalf;
+                    if (t >= 0 && t < cnth) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) sStage[(i < 2 ? i : i + 3) * (kStageHalf + 1) + t] = (double)vf[i];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) sStage[(kColC + i) * (kStageHalf + 1) + t] = vd[i];
+                    }
+                    wsync();
+                    if (hf == 1) fetch(j0 + kStageChunk + lane); // next chunk's gathers overlap the serial chains below
+                    if (chain && cnth > 0) {
+                        const double *src = sStage + myc * (kStageHalf + 1);
+                        if (cnth == kStageHalf) { // full half: LDS reads issue 16 at a time, only the adds are serial
+#pragma unroll
+                            for (int h = 0; h < kStageHalf; h += 16) {
+                                double v[16];
+#pragma unroll
+                                for (int q = 0; q < 16; ++q) v[q] = src[h + q];
+#pragma unroll
+                                for (int q = 0; q < 16; ++q) v[q] = is_sq ? v[q] * v[q] : v[q]; // ops.h:138 multiplyArrays (branch-free)
+#pragma unroll
+                                for (int q = 0; q < 16; ++q) acc = acc + v[q];          // ops.h:121 / 138 sumArrays
+                            }
+                        } else if (!is_sq) {
+                            for (int q = 0; q < cnth; ++q) acc = acc + src[q];
+                        } else {
+                            for (int q = 0; q < cnth; ++q) { const double v = src[q]; acc = acc + v * v; }
+                        }
+                    }
+                    wsync();
+                }
+            }
+            const double sq = __shfl(acc, (lane & 31) + 32, 64);
+            const double dn = (double)n;
+            const double mean = acc / dn;                      // ops.h:123
+            double sd = sqrt(sq / dn - mean * mean);           // ops.h:141
+            if (p.policy == RPF_DEGEN_EPS && isnan(sd)) sd = 0.0;
+            if (lane < kNDim) {
+                sStat[lane] = mean;
+                sStat[kNDim + lane] = sd;
+                if (p.dbg.mean) p.dbg.mean[pix * kNDim + lane] = mean;
+                if (p.dbg.stddev) p.dbg.stddev[pix * kNDim + lane] = sd;
+            }
+            // wave min / max of x per column -> sStat[38 + c], sStat[57 + c]
+            {
+                float a32[32];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { a32[i] = fmn[i]; a32[16 + i] = -fmx[i]; }
+                const float r = xl::reduce32<xl::OpMin>(a32, lane);
+                const int slot = xl::slot32(lane);
+                if ((lane & 1) == 0) {
+                    const int i = slot & 15;
+                    const int col = i < 2 ? i : i + 3;
+                    if (slot < 16) sStat[2 * kNDim + col] = (double)r;
+                    else sStat[3 * kNDim + col] = (double)(-r);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const double lo = xl::allreduce<xl::OpMin>(cmn[i]), hi = xl::allreduce<xl::OpMax>(cmx[i]);
+                    if (lane == 0) { sStat[2 * kNDim + kColC + i] = lo; sStat[3 * kNDim + kColC + i] = hi; }
+                }
+            }
+            wsync();
+        }
+
     }
 
     // ---------------- stage 3a: normalise, bin ids: bins_stage() above --------------------------
@@ -905,13 +1149,13 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
         default: if constexpr (K >= 8) bins_stage<8, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
         }
     } else {
-        bins_stage<K, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B);
+        bins_stage<K, KW, PACK5, NW>(p, sStat, sOff, sBinW, lane, n, B, wv);
     }
-    wsync();
-    if (p.dbg.bin_hash != nullptr && lane < kNDim) { // debug only: hash in sample order j = lane + 64*slot
+    bsync();
+    if (p.dbg.bin_hash != nullptr && tid < kNDim) { // debug only: hash in sample order j = lane + 64*slot
         uint32_t h = 2166136261u;
-        for (int j = 0; j < n; ++j) h = fnv1a_u16(h, bin_of_sample<KW, PACK5>(sBinW, lane, j));
-        p.dbg.bin_hash[pix * kNDim + lane] = h;
+        for (int j = 0; j < n; ++j) h = fnv1a_u16(h, bin_of_sample<KW, PACK5>(sBinW, tid, j));
+        p.dbg.bin_hash[pix * kNDim + tid] = h;
     }
     // ---------------- stage 3b: histograms -> mutual information: mi_stage() above ------------
     if (p.stage_mask & 4) {
@@ -941,14 +1185,14 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
             }
 #undef RPF_MI_CASE
         } else {
-            mi_stage<K, KW, 0, false, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);
+            mi_stage<K, KW, 0, false, PACK5, NW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B, wv);
         }
     }
-    wsync();
+    bsync();
     {
         const int64_t TNf = (int64_t)p.tfix[n];
         const double dn = (double)n;
-        for (int pr = lane; pr < kNPair; pr += kWave) {
+        for (int pr = tid; pr < kNPair; pr += kThreads) {
             const int ca = c_pairs.a[pr], cb = c_pairs.b[pr];
             const int64_t f = TNf + (int64_t)sPairF[pr] - (int64_t)sHXf[ca] - (int64_t)sHXf[cb];
             const double mi = ldexp((double)f, -kTFixBits) / dn;
@@ -956,14 +1200,15 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
             if (p.dbg.mi) p.dbg.mi[pix * kNPair + pr] = mi;
         }
     }
-    wsync();
+    bsync();
 
     // ---------------- stage 3c: alpha, beta, W_r_c (rpf.cpp:444-487), lane-parallel -----------------
     // lane k < 12 owns feature k, lane c < 3 also owns colour channel c; values meet through a scratch area in the
     // (now dead) histogram buffer: Drf[12] | Drc,Dpc,Dfc [9] | alpha[3] | beta[12] | wrc | coef[17]
-    double *sT = reinterpret_cast<double *>(sHist);
+    double *sT = reinterpret_cast<double *>(sHist0);
     double *sDrf = sT, *sD9 = sT + 12, *sAlpha = sT + 24, *sBeta = sT + 28, *sWrc = sT + 40, *sCoef = sT + 44;
-    {
+    int *sBadFlag = reinterpret_cast<int *>(sT + 64); // NW > 1: did any wave of the pixel see a NaN colour
+    if (NW == 1 || wv == 0) {
         const int k = min(lane, kNFeat - 1), c = min(lane, 2);
         const double Drf = 0.0 + sMI[k * 4 + 0] + sMI[k * 4 + 1]; // rpf.cpp:421
         const double Dpf = 0.0 + sMI[k * 4 + 2] + sMI[k * 4 + 3]; // rpf.cpp:425
@@ -1005,10 +1250,12 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
         }
         if (lane == 0) {
             sWrc[0] = wrc;
+            if (NW > 1) sBadFlag[0] = 0;
             if (p.dbg.wrc) p.dbg.wrc[pix] = wrc;
         }
         wsync();
     }
+    if constexpr (NW > 1) __syncthreads();
     const double wrc = sWrc[0];
 
     // ---------------- stage 4: weights and blend (rpf.cpp:627-717) ------------------------------
@@ -1031,8 +1278,8 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
             const double wkk = k < 2 ? 1.0 : (k < 5 ? sAlpha[k >= 2 && k < 5 ? k - 2 : 0] : sBeta[k >= 5 ? k - 5 : 0]);
             coefz[k] = (float)(wkk * (k < 2 ? inv2sp : inv2sc));
         }
-        wsync();
-        if (lane < 17) {
+        bsync(); // every wave has read alpha / beta: the coefficient slots may be overwritten
+        if (tid < 17) {
             const int col = lane < 5 ? lane : lane + 2;
             const double sd = sStat[kNDim + col];
             const double wkk = lane < 2 ? 1.0 : (lane < 5 ? sAlpha[max(lane - 2, 0)] : sBeta[max(lane - 5, 0)]);
@@ -1040,16 +1287,16 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
             sFastI[lane] = (sd == 0.0) ? 0.0 : 1.0 / sd; // SD == 0 normalises to z == 0 (ops.h:48)
             sCoef[lane] = wkk * (lane < 2 ? inv2sp : inv2sc); // cz_k (overwrites the raw-space coefficient slot)
         }
-        wsync();
+        bsync();
         if constexpr (FAST) {
-            for (int t = lane; t < S * 20; t += kWave) {
+            for (int t = tid; t < S * 20; t += kThreads) {
                 const int i = t / 20, k = t - i * 20;
                 float z = 0.f;
                 if (k < 17) z = (float)((sOwn[i * kNDim + (k < 5 ? k : k + 2)] - sFastM[k]) * sFastI[k]);
                 sFastZ[t] = z;
             }
         } else {
-            for (int i = lane; i < S; i += kWave) {
+            for (int i = tid; i < S; i += kThreads) {
                 double A = 0.0;
 #pragma unroll
                 for (int k = 0; k < 17; ++k) {
@@ -1061,11 +1308,15 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
                 sOwnU[i * 18 + 17] = A;
             }
         }
-        wsync();
+        bsync();
     }
     bool bad = false;
-    constexpr int kOwnBlock = 4; // own samples weighted per sweep over the neighbourhood (register budget: 3 waves/SIMD)
-    for (int i0 = 0; i0 < ((p.stage_mask & 8) ? S : 0); i0 += kOwnBlock) {
+    // own samples weighted per sweep over the neighbourhood (register budget: 4 at 3 waves/SIMD; the multi-wave kernels
+    // run 1-2 waves/SIMD and take 8, halving the per-sample set-up, and gather one sample slot ahead)
+    constexpr int kOwnBlock = NW > 1 ? 8 : 4;
+    double *sRed = sMI + 16 * wv; // 16 sums of a sweep meet here (the MI values are dead; one slot set per wave)
+    // NW > 1: the sweeps are dealt round-robin to the waves of the pixel
+    for (int i0 = kOwnBlock * wv; i0 < ((p.stage_mask & 8) ? S : 0); i0 += kOwnBlock * NW) {
         double sw[kOwnBlock], s0[kOwnBlock], s1[kOwnBlock], s2[kOwnBlock];
 #pragma unroll
         for (int ii = 0; ii < kOwnBlock; ++ii) { sw[ii] = 0.0; s0[ii] = 0.0; s1[ii] = 0.0; s2[ii] = 0.0; }
@@ -1081,12 +1332,13 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
                 for (int k = 0; k < 3; ++k) pc[k] = p.col_in[(uint64_t)k * p.plane_stride + off];
             }
         };
+        if constexpr (NW > 1) fetch17(lane);
         if constexpr (!FAST) {
 #pragma unroll 1
             for (int kk = 0; kk < K; ++kk) {
                 const int j = lane + kWave * kk;
                 if (j >= n) break;
-                fetch17(j); // no register double-buffering here: three waves per SIMD cover the gather latency
+                if constexpr (NW == 1) fetch17(j); // no register double-buffering: three waves per SIMD cover the gather latency
                 double zj[17], cj[3];
                 double Bj = 0.0;
 #pragma unroll
@@ -1098,6 +1350,7 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
                 }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) cj[k] = pc[k];
+                if constexpr (NW > 1) fetch17(j + kWave); // the next slot's gathers fly while this one is weighted
                 // straight-line over the kOwnBlock own samples (a missing one re-reads the last row and its weight is
                 // forced to 0) so their dependent chains interleave; the 17-term dot product runs as four partial sums
 #pragma unroll
@@ -1134,7 +1387,7 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
             for (int kk = 0; kk < K; ++kk) {
                 const int j = lane + kWave * kk;
                 if (j >= n) break;
-                fetch17(j);
+                if constexpr (NW == 1) fetch17(j);
                 float zj[17];
                 double cj[3];
                 zj[0] = (float)(((double)pf[0] - sFastM[0]) * sFastI[0]);
@@ -1143,6 +1396,7 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
                 for (int k = 0; k < 3; ++k) { cj[k] = pc[k]; zj[2 + k] = (float)((pc[k] - sFastM[2 + k]) * sFastI[2 + k]); }
 #pragma unroll
                 for (int k = 0; k < 12; ++k) zj[5 + k] = (float)(((double)pf[2 + k] - sFastM[5 + k]) * sFastI[5 + k]);
+                if constexpr (NW > 1) fetch17(j + kWave);
 #pragma unroll
                 for (int ii = 0; ii < kOwnBlock; ++ii) {
                     const int i = i0 + ii;
@@ -1170,19 +1424,20 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
             }
         }
         // 16 wave sums by one transposed butterfly, gathered through LDS: [0..3] sum w, [4..7] r, [8..11] g, [12..15] b
-        {
+#pragma unroll
+        for (int hb = 0; hb < kOwnBlock; hb += 4) {
             double ga[16];
 #pragma unroll
-            for (int ii = 0; ii < kOwnBlock; ++ii) { ga[ii] = sw[ii]; ga[4 + ii] = s0[ii]; ga[8 + ii] = s1[ii]; ga[12 + ii] = s2[ii]; }
+            for (int ii = 0; ii < 4; ++ii) { ga[ii] = sw[hb + ii]; ga[4 + ii] = s0[hb + ii]; ga[8 + ii] = s1[hb + ii]; ga[12 + ii] = s2[hb + ii]; }
             const double ta = xl::reduce16<xl::OpSum>(ga, lane);
             wsync();
-            if ((lane & 3) == 0) sMI[xl::slot16(lane)] = ta;
+            if ((lane & 3) == 0) sRed[xl::slot16(lane)] = ta;
             wsync();
-            if (lane < 3 * kOwnBlock) {
+            if (lane < 12) {
                 const int ii = lane / 3, k = lane % 3;
-                const int i = i0 + ii;
+                const int i = i0 + hb + ii;
                 if (i < S) {
-                    double prime = sMI[4 * (k + 1) + ii] / sMI[ii];       // rpf.cpp:700
+                    double prime = sRed[4 * (k + 1) + ii] / sRed[ii];     // rpf.cpp:700
                     if (isnan(prime)) {                                    // rpf.cpp:702: the reference exits here
                         bad = true;
                         if (p.policy == RPF_DEGEN_EPS) prime = sOwn[i * kNDim + kColC + k];
@@ -1192,7 +1447,14 @@ __global__ __launch_bounds__(64, (K <= 8 ? 3 : (K <= 13 ? 2 : 1))) void filter_p
             }
         }
     }
-    if (__any(bad) && lane == 0) {
+    if constexpr (NW > 1) {
+        if (__any(bad) && lane == 0) sBadFlag[0] = 1;
+        __syncthreads();
+        if (tid == 0 && sBadFlag[0]) {
+            atomicAdd(&p.status[0], 1);
+            atomicMin(&p.status[1], (int)pix);
+        }
+    } else if (__any(bad) && lane == 0) {
         atomicAdd(&p.status[0], 1);
         atomicMin(&p.status[1], (int)pix);
     }
@@ -1318,20 +1580,27 @@ __global__ __launch_bounds__(256) void nbhd_reduce_kernel(const int32_t *nbhd, u
     }
 }
 
-template <int K, bool TL, bool FAST>
+template <int K, bool TL, bool FAST, int NW>
 hipError_t launch_filter_inst(const PassParams &p, const LdsLayout &L, unsigned grid, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute((const void *)filter_pixel_kernel<K, TL, FAST>,
+    hipError_t e = hipFuncSetAttribute((const void *)filter_pixel_kernel<K, TL, FAST, NW>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((filter_pixel_kernel<K, TL, FAST>), dim3(grid), dim3(64), L.total, s, p, L);
+    hipLaunchKernelGGL((filter_pixel_kernel<K, TL, FAST, NW>), dim3(grid), dim3(64 * NW), L.total, s, p, L);
     return hipGetLastError();
 }
 template <int K>
 hipError_t launch_filter_k(const PassParams &p, const LdsLayout &L, bool t_in_lds, unsigned grid, hipStream_t s) {
-    if (p.fast_weights) {
-        return t_in_lds ? launch_filter_inst<K, true, true>(p, L, grid, s) : launch_filter_inst<K, false, true>(p, L, grid, s);
+    if constexpr (K >= 13) {
+        if (L.nw == 4) {
+            if (t_in_lds && !p.fast_weights) return launch_filter_inst<K, true, false, 4>(p, L, grid, s); // experiment
+            return p.fast_weights ? launch_filter_inst<K, false, true, 4>(p, L, grid, s)
+                                  : launch_filter_inst<K, false, false, 4>(p, L, grid, s);
+        }
     }
-    return t_in_lds ? launch_filter_inst<K, true, false>(p, L, grid, s) : launch_filter_inst<K, false, false>(p, L, grid, s);
+    if (p.fast_weights) {
+        return t_in_lds ? launch_filter_inst<K, true, true, 1>(p, L, grid, s) : launch_filter_inst<K, false, true, 1>(p, L, grid, s);
+    }
+    return t_in_lds ? launch_filter_inst<K, true, false, 1>(p, L, grid, s) : launch_filter_inst<K, false, false, 1>(p, L, grid, s);
 }
 
 } // namespace
@@ -1344,6 +1613,18 @@ int samples_per_lane(int nmax) {
     for (int k : ks)
         if (per_lane <= k) return k;
     return 0;
+}
+
+// waves per pixel: 4 once a neighbourhood is too large for more than a few one-wave workgroups to share a CU's
+// LDS (K >= 25: 32 spp and up at box 7); RPF_NW=1 / RPF_NW=4 override for experiments (4 needs K >= 13)
+int waves_per_pixel(int nmax) {
+    const int K = samples_per_lane(nmax);
+    int nw = K >= 25 ? 4 : 1;
+    if (const char *e = std::getenv("RPF_NW")) {
+        const int v = std::atoi(e);
+        if (v == 1 || (v == 4 && K >= 13)) nw = v;
+    }
+    return nw;
 }
 
 bool table_in_lds(int nmax) {
@@ -1367,7 +1648,10 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     L.off_own = o; o += align_up((uint32_t)S * kNDim * 8u, 16);
     L.off_off = o; o += align_up((uint32_t)nmax * 4u, 16);
     L.off_union = o;
-    const uint32_t stage = align_up(kNDim * (kStageHalf + 1) * 8, 16);
+    const int nw = waves_per_pixel(nmax);
+    L.nw = (uint32_t)nw;
+    const uint32_t stage = nw > 1 ? align_up((uint32_t)(nw - 1) * kNDim * (kStageChunk + 1) * 8u, 16) // one chunk per producer wave
+                                  : align_up(kNDim * (kStageHalf + 1) * 8, 16);
     const uint32_t bins = K <= 8 ? align_up((uint32_t)kNDim * kWave * 5u, 16)          // 5-bit words + slot-6 bytes
                                  : align_up((uint32_t)kNDim * kWave * KW * 4u, 16);     // 5- or 6-bit fields in KW words
     uint32_t uni = bins > stage ? bins : stage;
@@ -1377,7 +1661,9 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     L.off_hist = o;
     uint32_t cells = (uint32_t)bmax * (uint32_t)bmax;
     if (K <= 8 && cells < 512u) cells = 512u; // mi_stage clears with unconditional 1-KiB stores
-    o += align_up(cells * 4u, 16);
+    if (cells < 256u) cells = 256u;           // the buffer doubles as scratch (stage 1b masks, stage 3c, flags)
+    L.hist_stride = align_up(cells * 4u, 16);
+    o += L.hist_stride * (uint32_t)nw;        // one histogram buffer per wave of the pixel
     if (const char *e = std::getenv("RPF_LDS_PAD")) o += (uint32_t)std::atoi(e); // occupancy experiment knob
     L.total = o;
     return L;

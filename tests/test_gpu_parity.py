@@ -210,7 +210,8 @@ def test_feature_images_bit_exact(ctx, hipmod, oracle):
     assert (got[0, ..., 0] == 0).all() and got[2].max() == 1.0
 
 
-@pytest.mark.parametrize("W,H,S,box", [(10, 8, 64, 7), (14, 10, 8, 9), (12, 9, 2, 7), (21, 6, 8, 7)])
+@pytest.mark.parametrize("W,H,S,box", [(10, 8, 64, 7), (14, 10, 8, 9), (12, 9, 2, 7), (21, 6, 8, 7), (13, 9, 32, 7),
+                                       (9, 8, 20, 9)])
 def test_more_shapes_vs_oracle(ctx, hipmod, oracle, W, H, S, box):
     """the 49-samples-per-lane kernel (64 spp), a 9x9 box, 2 spp (B tiny: replicated-histogram path), a frame
     whose width is not a multiple of anything"""
@@ -218,6 +219,18 @@ def test_more_shapes_vs_oracle(ctx, hipmod, oracle, W, H, S, box):
     got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS), box=box)
     want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=box, policy=oracle.DEGEN_EPS))
     check_pass(got, want, ab_rtol=1e-6)
+
+
+@pytest.mark.parametrize("S,nw", [(16, "4"), (32, "1"), (64, "1")])
+def test_waves_per_pixel_variants_agree(ctx, hipmod, oracle, monkeypatch, S, nw):
+    """large neighbourhoods run four waves per pixel by default (32 spp and up), one otherwise; RPF_NW forces the
+    other variant: both must reproduce the oracle's discrete outcomes exactly"""
+    W, H = 11, 9
+    planes = fb.synth_planes(W, H, S, seed=31 + S, sigma_f=0.05, sigma_c=1e-4, mode="smooth")
+    want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7))
+    monkeypatch.setenv("RPF_NW", nw)
+    got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S), box=7)
+    check_pass(got, want)
 
 
 def test_small_neighbourhood_paths_vs_oracle(ctx, hipmod, oracle):
