@@ -144,7 +144,7 @@ int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const float *d_plan
     p.pmean = ctx->d_pmean; p.pstd = ctx->d_pstd; p.tfix = ctx->d_tfix; p.dfix = ctx->d_dfix;
     p.nbhd = ctx->d_nbhd; p.status = ctx->d_status;
     if (dbg_dev) p.dbg = *dbg_dev;
-    out.lds = lds_layout(p.S, p.nmax, p.bmax, table_in_lds(p.nmax)).total;
+    out.lds = lds_layout(p.S, p.nmax, p.bmax, table_in_lds(p.S, p.nmax, p.bmax)).total;
     if ((int)out.lds > max_lds_per_block())
         return fail(ctx, RPF_E_UNSUPPORTED, "neighbourhood working set exceeds 160 KiB of LDS");
     return RPF_OK;
@@ -426,7 +426,7 @@ int64_t rpf_lds_bytes_required(int32_t S, int32_t box) {
     const int nm = (int)nmax;
     int bmax = (int)std::sqrt((double)nm);
     if (bmax < 1) bmax = 1;
-    return lds_layout(S, nm, bmax, table_in_lds(nm)).total;
+    return lds_layout(S, nm, bmax, table_in_lds(S, nm, bmax)).total;
 }
 
 int32_t rpf_colour_from_planes_device(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, double *d_colour,

@@ -46,7 +46,7 @@ struct LdsLayout {
 };
 LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds);
 int samples_per_lane(int nmax); // the K the filter kernel is instantiated with (0 = unsupported)
-bool table_in_lds(int nmax);
+bool table_in_lds(int S, int nmax, int bmax);
 int waves_per_pixel(int nmax);
 
 hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s);

@@ -68,6 +68,13 @@ __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Workgroup barrier that publishes LDS traffic only: lgkmcnt(0) + s_barrier.  __syncthreads() also drains vmcnt, i.e.
+// it would wait for every gather a producer wave has in flight; here those gathers are meant to stay in flight across
+// the barrier (the compiler still waits on them, by register dependence, where their values are used).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ uint32_t fnv1a_u32(uint32_t h, uint32_t v) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { h ^= (v >> (8 * i)) & 0xffu; h *= 16777619u; }
@@ -908,32 +915,50 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
             const bool chain = myc < kNDim;
             const bool is_sq = lane >= 32;
             for (int r = 0; r < nround; ++r) {
-                __syncthreads(); // A
-#pragma unroll 1
-                for (int w = 0; w < NP; ++w) {
-                    const int cnt = min(kStageChunk, nrun - (r * NP + w) * kStageChunk); // wave-uniform
-                    if (cnt <= 0) break;
-                    if (chain) {
-                        const double *src = sStage + w * (kNDim * kCS) + myc * kCS;
-                        if (cnt == kStageChunk) { // LDS reads issue 16 at a time, only the adds are serial
+                lds_barrier(); // A
+                if (nrun - r * NP * kStageChunk >= NP * kStageChunk) {
+                    // full round: NP*4 batches of 16 staged values, the reads of batch t+1 issued before batch t is
+                    // summed (this wave is alone on its SIMD: nothing else hides the LDS latency)
+                    constexpr int NB = NP * (kStageChunk / 16);
+                    const double *col = sStage + (chain ? myc : 0) * kCS;
+                    double vb[2][16];
+                    auto load16 = [&](int t, double (&v)[16]) {
+                        const double *src = col + (t / 4) * (kNDim * kCS) + (t % 4) * 16;
 #pragma unroll
-                            for (int h = 0; h < kStageChunk; h += 16) {
+                        for (int q = 0; q < 16; ++q) v[q] = src[q];
+                    };
+                    load16(0, vb[0]);
+#pragma unroll
+                    for (int t = 0; t < NB; ++t) {
+                        if (t + 1 < NB) load16(t + 1, vb[(t + 1) & 1]);
+                        double (&v)[16] = vb[t & 1];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) v[q] = is_sq ? v[q] * v[q] : v[q]; // ops.h:138 multiplyArrays
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) acc = acc + v[q];                 // ops.h:121 / 138 sumArrays
+                    }
+                } else {
+#pragma unroll 1
+                    for (int w = 0; w < NP; ++w) {
+                        const int cnt = min(kStageChunk, nrun - (r * NP + w) * kStageChunk); // wave-uniform
+                        if (cnt <= 0) break;
+                        if (chain) {
+                            const double *src = sStage + w * (kNDim * kCS) + myc * kCS;
+                            int q0 = 0;
+                            for (; q0 + 16 <= cnt; q0 += 16) {
                                 double v[16];
 #pragma unroll
-                                for (int q = 0; q < 16; ++q) v[q] = src[h + q];
+                                for (int q = 0; q < 16; ++q) v[q] = src[q0 + q];
 #pragma unroll
-                                for (int q = 0; q < 16; ++q) v[q] = is_sq ? v[q] * v[q] : v[q]; // ops.h:138 multiplyArrays
+                                for (int q = 0; q < 16; ++q) v[q] = is_sq ? v[q] * v[q] : v[q];
 #pragma unroll
-                                for (int q = 0; q < 16; ++q) acc = acc + v[q];                 // ops.h:121 / 138 sumArrays
+                                for (int q = 0; q < 16; ++q) acc = acc + v[q];
                             }
-                        } else if (!is_sq) {
-                            for (int q = 0; q < cnt; ++q) acc = acc + src[q];
-                        } else {
-                            for (int q = 0; q < cnt; ++q) { const double v = src[q]; acc = acc + v * v; }
+                            for (int q = q0; q < cnt; ++q) { const double v = src[q]; acc = acc + (is_sq ? v * v : v); }
                         }
                     }
                 }
-                __syncthreads(); // B
+                lds_barrier(); // B
             }
             const double sq = __shfl(acc, (lane & 31) + 32, 64);
             const double dn = (double)n;
@@ -988,9 +1013,9 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
                         for (int i = 0; i < 3; ++i) sOwn[(j0 + lane) * kNDim + kColC + i] = vd[i];
                     }
                 }
-                __syncthreads(); // A
-                fetch(j0 + NP * kStageChunk + lane);
-                __syncthreads(); // B (also waits for the gathers just issued: wave 0 is chaining meanwhile)
+                fetch(j0 + NP * kStageChunk + lane); // in flight across both barriers, while wave 0 chains
+                lds_barrier(); // A
+                lds_barrier(); // B
             }
             // this wave's min / max of x per column -> sMM[wv-1][c], sMM[wv-1][19 + c]
             double *mm = sMM + (wv - 1) * (2 * kNDim);
@@ -1592,7 +1617,9 @@ template <int K>
 hipError_t launch_filter_k(const PassParams &p, const LdsLayout &L, bool t_in_lds, unsigned grid, hipStream_t s) {
     if constexpr (K >= 13) {
         if (L.nw == 4) {
-            if (t_in_lds && !p.fast_weights) return launch_filter_inst<K, true, false, 4>(p, L, grid, s); // experiment
+            if (t_in_lds)
+                return p.fast_weights ? launch_filter_inst<K, true, true, 4>(p, L, grid, s)
+                                      : launch_filter_inst<K, true, false, 4>(p, L, grid, s);
             return p.fast_weights ? launch_filter_inst<K, false, true, 4>(p, L, grid, s)
                                   : launch_filter_inst<K, false, false, 4>(p, L, grid, s);
         }
@@ -1604,6 +1631,8 @@ hipError_t launch_filter_k(const PassParams &p, const LdsLayout &L, bool t_in_ld
 }
 
 } // namespace
+
+int max_lds_per_block() { return 160 * 1024; }
 
 static uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 
@@ -1627,11 +1656,16 @@ int waves_per_pixel(int nmax) {
     return nw;
 }
 
-bool table_in_lds(int nmax) {
-    // The D table is read through L1 (3 .. 25 KiB of LDS per workgroup buy resident waves, which is what these
-    // latency-bound kernels need); RPF_TABLE_IN_LDS=1 restores the LDS copy for experiments.
-    const char *e = std::getenv("RPF_TABLE_IN_LDS");
-    return e && std::atoi(e) != 0 && (uint32_t)nmax * 8u <= 65536u;
+bool table_in_lds(int S, int nmax, int bmax) {
+    // One-wave kernels read the D table through L1: 3 .. 25 KiB of LDS per workgroup buy resident waves, which is what
+    // those latency-bound kernels need.  The four-wave kernels run 1-2 workgroups per CU, every table look-up is a
+    // round trip none of their few waves can cover, and one copy serves four waves: they keep the table in LDS
+    // whenever that costs no resident workgroup (32 spp: 161 -> 206 ms without it).  RPF_TABLE_IN_LDS=0/1 overrides.
+    if ((uint32_t)nmax * 8u > 65536u) return false;
+    if (const char *e = std::getenv("RPF_TABLE_IN_LDS")) return std::atoi(e) != 0;
+    if (waves_per_pixel(nmax) == 1) return false;
+    const uint32_t without = lds_layout(S, nmax, bmax, false).total, with = lds_layout(S, nmax, bmax, true).total;
+    return with <= (uint32_t)max_lds_per_block() && (uint32_t)max_lds_per_block() / with == (uint32_t)max_lds_per_block() / without;
 }
 
 LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
@@ -1669,7 +1703,6 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     return L;
 }
 
-int max_lds_per_block() { return 160 * 1024; }
 
 hipError_t launch_udiv_selftest(uint64_t n, uint64_t seed, int mode, unsigned long long *d_mismatch, hipStream_t s) {
     hipLaunchKernelGGL(udiv_selftest_kernel, dim3(2048), dim3(256), 0, s, n, seed, mode, d_mismatch);
@@ -1686,7 +1719,7 @@ hipError_t launch_pixel_stats_rows(const PassParams &p, int r0, int r1, hipStrea
 hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s) { return launch_pixel_stats_rows(p, 0, p.H, s); }
 
 hipError_t launch_filter_pass(const PassParams &p, hipStream_t s, uint32_t *lds_bytes_out) {
-    const bool t_in_lds = table_in_lds(p.nmax);
+    const bool t_in_lds = table_in_lds(p.S, p.nmax, p.bmax);
     const LdsLayout L = lds_layout(p.S, p.nmax, p.bmax, t_in_lds);
     if (lds_bytes_out) *lds_bytes_out = L.total;
     if ((int)L.total > max_lds_per_block()) return hipErrorInvalidValue;
