@@ -35,6 +35,8 @@ struct rpf_ctx {
     float *d_prgb = nullptr;     size_t cap_prgb = 0;
     int32_t *d_status = nullptr;                           // [0] bad count [1] first bad
     unsigned long long *d_nred = nullptr;                  // [0] sum N [1] max N
+    uint32_t *d_lists = nullptr; size_t cap_lists = 0;     // size binning: [7][H*W] pixel lists
+    uint32_t *d_class_counts = nullptr;                    // [7]
     // debug planes
     void *d_dbg[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_dbg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -152,6 +154,41 @@ int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const float *d_plan
 
 int32_t finish_counters(rpf_ctx *ctx, const rpf_desc *d, hipStream_t s);
 
+// One fused-filter pass over rows [p.row_begin, p.row_end).  When box*box*S is above what the one-wave kernels hold
+// (512 samples), the neighbourhood sizes are counted first and every kernel family filters its own pixel list with
+// LDS sized for its capacity (rpf_kernels.hip, "neighbourhood-size binning"); RPF_BINNING=0/1 overrides.
+// Needs stage 1a's planes (pmean / pstd) for those rows.  Synchronises the stream when it bins (list sizes).
+int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p, hipStream_t s, int *launches) {
+    bool bin = p.nmax > 512;
+    if (const char *e = std::getenv("RPF_BINNING")) bin = std::atoi(e) != 0;
+    if (p.dbg.nbhd_size || p.dbg.mi) { /* debug planes are written by whichever launch owns the pixel: fine */ }
+    if (!bin) {
+        HIP_TRY(launch_filter_pass(p, s, nullptr));
+        if (launches) ++*launches;
+        return RPF_OK;
+    }
+    const size_t HW = (size_t)p.W * p.H;
+    int32_t st;
+    if ((st = ensure(ctx, ctx->d_lists, ctx->cap_lists, (size_t)kNumClasses * HW * sizeof(uint32_t)))) return st;
+    HIP_TRY(hipMemsetAsync(ctx->d_class_counts, 0, kNumClasses * sizeof(uint32_t), s));
+    HIP_TRY(launch_nbhd_count(p, s));
+    HIP_TRY(launch_classify(p, ctx->d_lists, ctx->d_class_counts, s));
+    uint32_t counts[kNumClasses];
+    HIP_TRY(hipMemcpyAsync(counts, ctx->d_class_counts, sizeof(counts), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int c = 0; c < kNumClasses; ++c) {
+        if (counts[c] == 0) continue;
+        PassParams q = p;
+        q.nmax = std::min(p.nmax, class_capacity(c));
+        q.bmax = std::max(1, (int)std::sqrt((double)q.nmax));
+        q.pix_list = ctx->d_lists + (size_t)c * HW;
+        q.list_count = counts[c];
+        HIP_TRY(launch_filter_pass(q, s, nullptr));
+        if (launches) ++*launches;
+    }
+    return RPF_OK;
+}
+
 // runs all passes of desc on device-resident buffers; colour ends up in d_colour
 int32_t run_passes(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, double *d_colour, hipStream_t s) {
     const bool timing = (d->flags & RPF_FLAG_TIMING) != 0;
@@ -178,7 +215,7 @@ int32_t run_passes(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, doubl
         // stage 1a depends on the features only: formed once (the reference recomputes identical values per pass)
         if (i == 0) HIP_TRY(launch_pixel_stats(ps_.p, s));
         if (timing) HIP_TRY(hipEventRecord(ctx->ev[2], s));
-        HIP_TRY(launch_filter_pass(ps_.p, s, nullptr));
+        if ((st = launch_filter_binned(ctx, ps_.p, s, &c.filter_kernel_launches))) return st;
         if (timing) {
             HIP_TRY(hipEventRecord(ctx->ev[3], s));
             HIP_TRY(hipEventSynchronize(ctx->ev[3]));
@@ -188,7 +225,6 @@ int32_t run_passes(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, doubl
             ms_stats += a;
             ms_filter += b;
         }
-        c.filter_kernel_launches++;
         std::swap(cin, cout);
     }
     if (cin != d_colour) HIP_TRY(hipMemcpyAsync(d_colour, cin, 3 * ps * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -291,16 +327,13 @@ int32_t run_host_pipeline(rpf_ctx *ctx, const rpf_desc *d, const float *planes, 
                 e = launch_copy_colour_span(cin, cout, ps, (uint64_t)b0 * row, (uint64_t)(b1 - b0) * row, s);
             return e;
         };
-        auto filter_rows = [&](int r0, int r1) -> hipError_t {
+        auto filter_rows = [&](int r0, int r1) -> int32_t {
             PassParams q = ps_.p;
             q.row_begin = std::max(r0, d->row_begin);
             q.row_end = std::min(r1, d->row_end);
-            hipError_t e = pass_through(r0, r1);
-            if (e == hipSuccess && q.row_end > q.row_begin) {
-                e = launch_filter_pass(q, s, nullptr);
-                c.filter_kernel_launches++;
-            }
-            return e;
+            HIP_TRY(pass_through(r0, r1));
+            if (q.row_end > q.row_begin) return launch_filter_binned(ctx, q, s, &c.filter_kernel_launches);
+            return RPF_OK;
         };
         auto emit_rows = [&](int j) -> int32_t { // last pass: reduce + download band j
             if (!want_out) return RPF_OK;
@@ -320,7 +353,7 @@ int32_t run_host_pipeline(rpf_ctx *ctx, const rpf_desc *d, const float *planes, 
             return RPF_OK;
         };
         if (!first && !last) { // middle passes: one launch over the slab
-            HIP_TRY(filter_rows(0, H));
+            if ((st = filter_rows(0, H))) return st;
         } else {
             for (int j = 0; j < nb; ++j) {
                 const Band &bd = bands[j];
@@ -336,16 +369,16 @@ int32_t run_host_pipeline(rpf_ctx *ctx, const rpf_desc *d, const float *planes, 
                     HIP_TRY(launch_colour_from_planes_span(ctx->d_planes, cin, ps, o, n, s));
                     HIP_TRY(launch_pixel_stats_rows(ps_.p, bd.r0, bd.r1, s));
                     if (j >= 1) { // band j-1 has its lower halo now
-                        HIP_TRY(filter_rows(bands[j - 1].r0, bands[j - 1].r1));
+                        if ((st = filter_rows(bands[j - 1].r0, bands[j - 1].r1))) return st;
                         if (last && (st = emit_rows(j - 1))) return st;
                     }
                 } else {
-                    HIP_TRY(filter_rows(bd.r0, bd.r1));
+                    if ((st = filter_rows(bd.r0, bd.r1))) return st;
                     if ((st = emit_rows(j))) return st;
                 }
             }
             if (first) {
-                HIP_TRY(filter_rows(bands[nb - 1].r0, bands[nb - 1].r1));
+                if ((st = filter_rows(bands[nb - 1].r0, bands[nb - 1].r1))) return st;
                 if (last && (st = emit_rows(nb - 1))) return st;
             }
         }
@@ -394,6 +427,7 @@ int32_t rpf_create(rpf_ctx **out, int32_t device) {
     HIP_TRY(hipStreamCreateWithFlags(&ctx->s_down, hipStreamNonBlocking));
     HIP_TRY(hipMalloc((void **)&ctx->d_status, 2 * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->d_nred, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&ctx->d_class_counts, kNumClasses * sizeof(uint32_t)));
     for (auto &e : ctx->ev) HIP_TRY(hipEventCreate(&e));
     return RPF_OK;
 }
@@ -403,7 +437,8 @@ void rpf_destroy(rpf_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *bufs[] = {ctx->d_planes, ctx->d_rayw, ctx->d_colA, ctx->d_colB, ctx->d_pmean, ctx->d_pstd, ctx->d_nbhd,
-                    ctx->d_tfix, ctx->d_dfix, ctx->d_srgb, ctx->d_prgb, ctx->d_status, ctx->d_nred};
+                    ctx->d_tfix, ctx->d_dfix, ctx->d_srgb, ctx->d_prgb, ctx->d_status, ctx->d_nred, ctx->d_lists,
+                    ctx->d_class_counts};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (void *b : ctx->d_dbg)
@@ -598,7 +633,8 @@ int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *d, int32_t box, cons
     const bool timing = (d->flags & RPF_FLAG_TIMING) != 0;
     HIP_TRY(launch_pixel_stats(ps_.p, s));
     if (timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
-    HIP_TRY(launch_filter_pass(ps_.p, s, nullptr));
+    int n_launch = 0;
+    if ((st = launch_filter_binned(ctx, ps_.p, s, &n_launch))) return st;
     if (timing) HIP_TRY(hipEventRecord(ctx->ev[1], s));
     HIP_TRY(launch_nbhd_reduce(ctx->d_nbhd, d->W, d->row_begin, d->row_end, ctx->d_nred, s));
     HIP_TRY(hipMemcpyAsync(colour_out, ctx->d_colB, 3 * ps * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -618,7 +654,7 @@ int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *d, int32_t box, cons
     c.max_nbhd = (int32_t)nred[1];
     c.nonfinite_pixels = hst[0];
     c.first_bad_pixel = hst[0] ? hst[1] : -1;
-    c.filter_kernel_launches = 1;
+    c.filter_kernel_launches = n_launch;
     if (timing) HIP_TRY(hipEventElapsedTime(&c.filter_kernel_ms, ctx->ev[0], ctx->ev[1]));
     if (hst[0] && d->degenerate_policy == RPF_DEGEN_REF_ABORT)
         return fail(ctx, RPF_E_NONFINITE, "non-finite filtered colour (the reference exits here, rpf.cpp:702-705)");

@@ -35,6 +35,8 @@ struct PassParams {
     const uint64_t *tfix;  // round(k ln k * 2^44), k = 0..nmax
     const uint64_t *dfix;  // tfix[k+1] - tfix[k], k = 0..nmax-1
     int32_t *nbhd;         // [H*W] N per pixel (always written)
+    const uint32_t *pix_list; // size-binned launch: the pixels (y*W+x) this launch filters, or null = every pixel of the slab
+    uint32_t list_count;
     int32_t *status;       // [0] count of NaN pixels, [1] lowest bad pixel index (atomicMin)
     rpf_debug dbg;         // device pointers, any may be null
 };
@@ -52,6 +54,11 @@ int waves_per_pixel(int nmax);
 hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s);
 hipError_t launch_pixel_stats_rows(const PassParams &p, int r0, int r1, hipStream_t s);
 hipError_t launch_filter_pass(const PassParams &p, hipStream_t s, uint32_t *lds_bytes_out);
+// neighbourhood-size binning (large box*box*S): count N per pixel, then deal the pixels into one list per kernel family
+constexpr int kNumClasses = 7;
+int class_capacity(int c);          // 64, 128, 256, 448, 832, 1600, 3136
+hipError_t launch_nbhd_count(const PassParams &p, hipStream_t s);
+hipError_t launch_classify(const PassParams &p, uint32_t *lists /*[7][H*W]*/, uint32_t *counts /*[7], zeroed*/, hipStream_t s);
 hipError_t launch_colour_from_planes(const float *planes, double *colour, uint64_t plane_stride, hipStream_t s);
 hipError_t launch_colour_from_planes_span(const float *planes, double *colour, uint64_t plane_stride, uint64_t e0,
                                           uint64_t cnt, hipStream_t s);

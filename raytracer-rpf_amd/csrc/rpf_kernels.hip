@@ -680,6 +680,37 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
     }
 }
 
+// XCD- and L2-aware pixel order of a slab.  Blocks with equal (blockIdx % 8) share an XCD and its 4 MiB L2: XCD r
+// filters one contiguous band of rows, and walks it in vertical strips of kStripW pixels (row by row inside a strip),
+// so the 7-row window data of the ~256 pixels in flight on the XCD (and the 6 rows shared with the next strip row)
+// stay L2-resident instead of being re-fetched once per image row.  (r, ql) -> pixel; false = no such pixel.
+__device__ __forceinline__ bool slab_pixel(const PassParams &p, int r, int64_t ql, int &x, int &y) {
+    constexpr int kStripW = 128;
+    const int W = p.W;
+    const int rows_own = p.row_end - p.row_begin;
+    const int rows_band = (rows_own + 7) / 8;
+    const int band_row0 = r * rows_band;
+    const int band_rows = min(rows_band, rows_own - band_row0);
+    if (band_rows <= 0) return false;
+    if (ql >= (int64_t)band_rows * W) return false;
+    const int full_strips = W / kStripW;
+    const int64_t strip_px = (int64_t)kStripW * band_rows;
+    int yl;
+    if (ql < full_strips * strip_px) {
+        const int sidx = (int)(ql / strip_px);
+        const int rr = (int)(ql - sidx * strip_px);
+        yl = rr / kStripW;
+        x = sidx * kStripW + (rr - yl * kStripW);
+    } else {
+        const int tw = W - full_strips * kStripW;
+        const int rr = (int)(ql - full_strips * strip_px);
+        yl = rr / tw;
+        x = full_strips * kStripW + (rr - yl * tw);
+    }
+    y = p.row_begin + band_row0 + yl;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // the fused per-pixel kernel
 //   K         compile-time bound on samples per lane: K*64 >= nmax ; lane owns samples j = lane + 64*kk
@@ -715,33 +746,19 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
     constexpr int kThreads = kWave * NW;
     const int W = p.W, H = p.H, S = p.S, b = p.b;
 
-    // XCD- and L2-aware pixel assignment.  Blocks with equal (blockIdx % 8) share an XCD and its 4 MiB L2:
-    // XCD r filters one contiguous band of rows, and walks it in vertical strips of kStripW pixels (row by row
-    // inside a strip), so the 7-row window data of the ~256 pixels in flight on the XCD (and the 6 rows shared
-    // with the next strip row) stay L2-resident instead of being re-fetched once per image row.
-    constexpr int kStripW = 128;
-    const int rows_own = p.row_end - p.row_begin;
-    const int rows_band = (rows_own + 7) / 8;
-    const int band_row0 = (int)(blockIdx.x & 7) * rows_band;
-    const int band_rows = min(rows_band, rows_own - band_row0);
-    if (band_rows <= 0) return;
-    const int64_t ql = (int64_t)(blockIdx.x >> 3);
-    if (ql >= (int64_t)band_rows * W) return;
-    const int full_strips = W / kStripW;
-    const int64_t strip_px = (int64_t)kStripW * band_rows;
-    int x, yl;
-    if (ql < full_strips * strip_px) {
-        const int sidx = (int)(ql / strip_px);
-        const int r = (int)(ql - sidx * strip_px);
-        yl = r / kStripW;
-        x = sidx * kStripW + (r - yl * kStripW);
-    } else {
-        const int tw = W - full_strips * kStripW;
-        const int r = (int)(ql - full_strips * strip_px);
-        yl = r / tw;
-        x = full_strips * kStripW + (r - yl * tw);
+    // pixel of this workgroup: see slab_pixel(); a size-binned launch walks its pixel list instead, dealt to the
+    // XCDs in eight contiguous chunks (the list is in slab_pixel order, so a chunk is again a band of strips)
+    int x, y;
+    if (p.pix_list != nullptr) {
+        const uint32_t chunk = (p.list_count + 7u) / 8u;
+        const uint32_t ql = blockIdx.x >> 3, e = (blockIdx.x & 7u) * chunk + ql;
+        if (ql >= chunk || e >= p.list_count) return;
+        const uint32_t pp = p.pix_list[e];
+        y = (int)(pp / (uint32_t)W);
+        x = (int)(pp - (uint32_t)y * (uint32_t)W);
+    } else if (!slab_pixel(p, (int)(blockIdx.x & 7), (int64_t)(blockIdx.x >> 3), x, y)) {
+        return;
     }
-    const int y = p.row_begin + band_row0 + yl;
     const uint64_t HW = (uint64_t)H * W;
     const uint64_t pix = (uint64_t)y * W + x;
 
@@ -823,7 +840,8 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
         for (int blk = wv; blk < nblk; blk += NW) {
             const int base = S + __shfl(excl, blk, kWave);
             const unsigned long long mask = sMask[blk];
-            if ((mask >> lane) & 1ull) sOff[base + __popcll(mask & ((1ull << lane) - 1ull))] = cand_off(blk * kWave + lane);
+            const int at = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (((mask >> lane) & 1ull) && at < p.nmax) sOff[at] = cand_off(blk * kWave + lane);
         }
         n = S + __shfl(incl, kWave - 1, kWave);
     } else {
@@ -869,7 +887,8 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
                         if (a >= lim12[k]) pass = false;       // allLessThan: fails iff a >= b (ops.h:101-104)
                     }
                     const unsigned long long mask = __ballot(pass);
-                    if (pass) sOff[n + __popcll(mask & ((1ull << lane) - 1ull))] = ob[u];
+                    const int at = n + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (pass && at < p.nmax) sOff[at] = ob[u]; // (at < nmax always: the bound only guards LDS)
                     n += __popcll(mask);
                     issue1(qb + kWave * kPF1 + lane, fb[u], ob[u]);
                 }
@@ -1485,6 +1504,95 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
     }
 }
 
+// ---- neighbourhood-size binning -----------------------------------------------------------------------------------
+// The cost and the LDS footprint of a pixel are set by its neighbourhood size N, and N is data dependent: box*box*S is
+// only its ceiling (path-traced buffers keep little more than the S own samples).  When the ceiling is above
+// what the one-wave kernels hold, N is counted first (stage 1b's test without the list), the pixels are dealt into one
+// list per kernel family, and every family filters its own list with LDS sized for ITS capacity.
+__global__ __launch_bounds__(256) void nbhd_count_kernel(PassParams p) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int W = p.W, H = p.H, S = p.S, b = p.b;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= (int64_t)(p.row_end - p.row_begin) * W) return; // wave-uniform
+    const int y = p.row_begin + (int)(q / W), x = (int)(q % W);
+    const uint64_t HW = (uint64_t)H * W, pix = (uint64_t)y * W + x;
+    const int x0 = max(x - b, 0), x1 = min(x + b, W - 1);
+    const int y0 = max(y - b, 0), y1 = min(y + b, H - 1);
+    const int nyv = y1 - y0 + 1;
+    const int centre_rank = (x - x0) * nyv + (y - y0);
+    const int ncand = ((x1 - x0 + 1) * nyv - 1) * S;
+    double m12[kNFeat], lim12[kNFeat];
+#pragma unroll
+    for (int k = 0; k < kNFeat; ++k) {
+        m12[k] = p.pmean[(uint64_t)k * HW + pix];
+        lim12[k] = p.pstd[(uint64_t)k * HW + pix] * 3.0; // multiplyArray(std, 3), rpf.cpp:579
+    }
+    constexpr int kPF1 = 3;
+    float fb[kPF1][kNFeat];
+    auto issue1 = [&](int qq, float (&f)[kNFeat]) {
+        if (qq < ncand) {
+            int cell = qq / S;
+            const int s = qq - cell * S;
+            if (cell >= centre_rank) ++cell;          // rpf.cpp:565
+            const int ix = cell / nyv, iy = cell - ix * nyv;
+            const uint32_t off = (uint32_t)(((uint64_t)(y0 + iy) * W + (x0 + ix)) * S + s);
+#pragma unroll
+            for (int k = 0; k < kNFeat; ++k) f[k] = p.planes[(uint64_t)(kColF + k) * p.plane_stride + off];
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < kPF1; ++u) issue1(u * kWave + lane, fb[u]);
+    int n = S;
+#pragma unroll 1
+    for (int q0 = 0; q0 < ncand; q0 += kWave * kPF1) {
+#pragma unroll
+        for (int u = 0; u < kPF1; ++u) {
+            const int qb = q0 + u * kWave;
+            if (qb < ncand) { // wave-uniform
+                bool pass = (qb + lane) < ncand;
+#pragma unroll
+                for (int k = 0; k < kNFeat; ++k) {
+                    const double a = fabs((double)fb[u][k] - m12[k]);
+                    if (a >= lim12[k]) pass = false;       // allLessThan (ops.h:101-104)
+                }
+                n += __popcll(__ballot(pass));
+                issue1(qb + kWave * kPF1 + lane, fb[u]);
+            }
+        }
+    }
+    if (lane == 0) p.nbhd[pix] = n;
+}
+
+struct ClassCaps { int cap[kNumClasses]; };
+
+// pixels in slab_pixel order -> one list per class (class = first capacity >= N); lists[c][*], counts[c]
+__global__ __launch_bounds__(256) void classify_kernel(PassParams p, ClassCaps caps, uint32_t *lists, uint32_t *counts,
+                                                       uint64_t list_stride) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int rows_band = (p.row_end - p.row_begin + 7) / 8;
+    const int64_t per_band = (int64_t)rows_band * p.W;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int x = 0, y = 0, cls = -1;
+    uint32_t pix = 0;
+    if (t < 8 * per_band && slab_pixel(p, (int)(t / per_band), t % per_band, x, y)) {
+        pix = (uint32_t)y * (uint32_t)p.W + (uint32_t)x;
+        const int n = p.nbhd[pix];
+        cls = kNumClasses - 1;
+#pragma unroll
+        for (int c = kNumClasses - 2; c >= 0; --c)
+            if (n <= caps.cap[c]) cls = c;
+    }
+#pragma unroll
+    for (int c = 0; c < kNumClasses; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if (m == 0ull) continue; // wave-uniform
+        uint32_t base = 0;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&counts[c], (uint32_t)__popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1, kWave);
+        if (cls == c) lists[(uint64_t)c * list_stride + base + __popcll(m & ((1ull << lane) - 1ull))] = pix;
+    }
+}
+
 // self-test of udiv(): bitwise comparison with the compiler's IEEE division on pseudo-random operands
 // drawn from the magnitudes stage 3a sees (and a band of extreme ones that must take the fallback)
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
@@ -1725,7 +1833,9 @@ hipError_t launch_filter_pass(const PassParams &p, hipStream_t s, uint32_t *lds_
     if ((int)L.total > max_lds_per_block()) return hipErrorInvalidValue;
     const int rows_own = p.row_end - p.row_begin;
     if (rows_own <= 0) return hipSuccess;
-    const int64_t band = (int64_t)((rows_own + 7) / 8) * p.W; // pixels per XCD band (see the kernel's mapping)
+    if (p.pix_list != nullptr && p.list_count == 0) return hipSuccess;
+    const int64_t band = p.pix_list ? (int64_t)((p.list_count + 7u) / 8u)
+                                    : (int64_t)((rows_own + 7) / 8) * p.W; // pixels per XCD band (see slab_pixel)
     const unsigned grid = (unsigned)(band * 8);
     switch (samples_per_lane(p.nmax)) {
     case 1: return launch_filter_k<1>(p, L, t_in_lds, grid, s);
@@ -1737,6 +1847,28 @@ hipError_t launch_filter_pass(const PassParams &p, hipStream_t s, uint32_t *lds_
     case 49: return launch_filter_k<49>(p, L, t_in_lds, grid, s);
     default: return hipErrorInvalidValue;
     }
+}
+
+int class_capacity(int c) {
+    static const int caps[kNumClasses] = {64, 128, 256, 448, 832, 1600, 3136}; // 64 * {1, 2, 4, 7, 13, 25, 49}
+    return caps[c];
+}
+
+hipError_t launch_nbhd_count(const PassParams &p, hipStream_t s) {
+    const int64_t npix = (int64_t)(p.row_end - p.row_begin) * p.W;
+    if (npix <= 0) return hipSuccess;
+    hipLaunchKernelGGL(nbhd_count_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_classify(const PassParams &p, uint32_t *lists, uint32_t *counts, hipStream_t s) {
+    const int64_t total = (int64_t)((p.row_end - p.row_begin + 7) / 8) * p.W * 8;
+    if (total <= 0) return hipSuccess;
+    ClassCaps caps;
+    for (int c = 0; c < kNumClasses; ++c) caps.cap[c] = class_capacity(c);
+    hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, caps, lists, counts,
+                       (uint64_t)p.H * p.W);
+    return hipGetLastError();
 }
 
 hipError_t launch_colour_from_planes_span(const float *planes, double *colour, uint64_t ps, uint64_t e0, uint64_t cnt,
