@@ -177,9 +177,11 @@ def main():
                    "parallelism": "row slabs x%d, 3-row colour halo over RCCL send/recv" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic("%dx%dx%d_box%d" % (W, args.rows_per_gpu, S, box)),
-                     "kernel": "filter_pixel_kernel", "kernel_ms": k_ms,
+                     "kernel": "filter_pixel_kernel", "kernel_ms": k_ms, "kernel_launches_per_step": cnt.filter_kernel_launches,
                      "algorithmic_bytes_per_launch": algo_bytes,
-                     "note": "the kernel is LDS-atomic/fp64-VALU bound (~350 ops/B, SURVEY 8d), not HBM bound"},
+                     "note": "the kernel is LDS-atomic/fp64-VALU bound (~350 ops/B, SURVEY 8d), not HBM bound; with "
+                             "box*box*S > 512 a step is nbhd_count + classify + one filter launch per occupied size class, "
+                             "and kernel_ms is their sum"},
     }
     # the pipe that actually bounds the fused kernel: LDS histogram atomics (19 marginal + 96 joint histograms per
     # pixel, one increment per neighbourhood sample each).  Peak = measured ds_add_rtn_u32 rate on random cells
