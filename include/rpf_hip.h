@@ -143,9 +143,9 @@ int32_t rpf_host_free(rpf_ctx *ctx, void *ptr); /* ctx may be NULL */
 
 /* Same pass structure with every buffer already resident in HBM (device pointers).  d_colour is 3 fp64
  * planes [3][H][W][S], read as the input colours and overwritten with the filtered ones; planes 2..4 of
- * d_planes are ignored.  Runs on `stream` (a hipStream_t, NULL = the context's own stream) and does not
- * synchronise unless RPF_FLAG_TIMING or the REF_ABORT status check require it (it does: status is read
- * back at the end). */
+ * d_planes are ignored.  Runs on `stream`: the hipStream_t on which the caller produced the buffers (NULL = the
+ * legacy default stream, e.g. PyTorch's default stream), so the pass is ordered after that work without an explicit
+ * synchronisation.  Returns after the stream has drained (the status and the counters are read back). */
 int32_t rpf_filter_device(rpf_ctx *ctx, const rpf_desc *desc, const float *d_planes, double *d_colour,
                           void *stream);
 

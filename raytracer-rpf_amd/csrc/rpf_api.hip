@@ -470,7 +470,7 @@ int32_t rpf_colour_from_planes_device(rpf_ctx *ctx, const rpf_desc *d, const flo
     if (st) return st;
     if (!d_planes || !d_colour) return fail(ctx, RPF_E_BADARG, "NULL device pointer");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t s = (hipStream_t)stream; // NULL = the legacy default stream: ordered after the caller's own work
     HIP_TRY(launch_colour_from_planes(d_planes, d_colour, (uint64_t)d->W * d->H * d->S, s));
     return RPF_OK;
 }
@@ -481,7 +481,7 @@ int32_t rpf_reduce_device(rpf_ctx *ctx, const rpf_desc *d, const double *d_colou
     if (st) return st;
     if (!d_colour) return fail(ctx, RPF_E_BADARG, "NULL device pointer");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t s = (hipStream_t)stream; // NULL = the legacy default stream: ordered after the caller's own work
     HIP_TRY(launch_reduce(d_colour, d_ray_weight, d_sample_rgb_out, d_pixel_rgb_out, d->W, d->H, d->S, s));
     return RPF_OK;
 }
@@ -491,7 +491,7 @@ int32_t rpf_filter_device(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes
     if (st) return st;
     if (!d_planes || !d_colour) return fail(ctx, RPF_E_BADARG, "NULL device pointer");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t s = (hipStream_t)stream; // NULL = the legacy default stream: ordered after the caller's own work
     return run_passes(ctx, d, d_planes, d_colour, s);
 }
 

@@ -211,7 +211,7 @@ def test_feature_images_bit_exact(ctx, hipmod, oracle):
 
 
 @pytest.mark.parametrize("W,H,S,box", [(10, 8, 64, 7), (14, 10, 8, 9), (12, 9, 2, 7), (21, 6, 8, 7), (13, 9, 32, 7),
-                                       (9, 8, 20, 9)])
+                                       (9, 8, 20, 9), (20, 18, 8, 17), (16, 12, 4, 11)])
 def test_more_shapes_vs_oracle(ctx, hipmod, oracle, W, H, S, box):
     """the 49-samples-per-lane kernel (64 spp), a 9x9 box, 2 spp (B tiny: replicated-histogram path), a frame
     whose width is not a multiple of anything"""
@@ -325,14 +325,20 @@ def test_host_plane_film_producer_equals_sampling_film(hipmod, oracle):
     assert rel_l2(srgb.astype(np.float64), c) <= REL_L2_BAR
 
 
-def test_full_size_1080p_properties(ctx, hipmod, oracle):
-    """BASELINE configs[1] (1920x1080x8spp) through size-independent properties: determinism, neighbourhood
-    size bounds, convex-combination bounds of every filtered colour, slab == full frame on a band, and the
-    oracle on a few full-width rows."""
+@pytest.mark.parametrize("W,H,S,mode,sf,sc,R", [
+    (1920, 1080, 8, "clustered", 1e-3, 0.01, 3),   # BASELINE configs[1]
+    (3840, 96, 32, "smooth", 0.05, 1e-4, 1),       # configs[3], one rank's slab cut short: N ~ 1500 (four-wave kernel)
+    (3840, 64, 32, "clustered", 1e-3, 0.01, 1),    # same shape, small neighbourhoods: several size classes per pass
+    (1920, 48, 64, "smooth", 0.05, 1e-4, 1),       # 64 spp: N ~ 3000
+])
+def test_full_size_properties(ctx, hipmod, oracle, W, H, S, mode, sf, sc, R):
+    """BASELINE-size buffers through size-independent properties: determinism, neighbourhood size bounds,
+    convex-combination bounds of every filtered colour, slab == full frame on a band, and the oracle on R full-width
+    rows."""
     import torch
-    W, H, S, b = 1920, 1080, 8, 3
+    b = 3
     dev = torch.device("cuda", 0)
-    planes = fb.synth_planes(W, H, S, xp=fb.torch_backend(dev), mode="clustered", sigma_f=1e-3, sigma_c=0.01).contiguous()
+    planes = fb.synth_planes(W, H, S, xp=fb.torch_backend(dev), mode=mode, sigma_f=sf, sigma_c=sc).contiguous()
     col0 = planes[2:5].to(torch.float64).contiguous()
     desc = hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS)
     outs = []
@@ -354,19 +360,20 @@ def test_full_size_1080p_properties(ctx, hipmod, oracle):
     out = outs[0]
     tol = 1e-9
     assert bool((out >= wmin[..., None] - tol).all()) and bool((out <= wmax[..., None] + tol).all())
-    # a 64-row slab with halo reproduces the same rows
-    a0, a1 = 500, 564
+    # a slab with halo reproduces the same rows
+    a0 = H // 2 - min(32, H // 4)
+    a1 = a0 + 2 * min(32, H // 4)
     sub = planes[:, a0 - b:a1 + b].contiguous()
     csub = sub[2:5].to(torch.float64).contiguous()
     d2 = hipmod.make_desc(W, a1 - a0 + 2 * b, S, row_begin=b, row_end=b + a1 - a0, policy=hipmod.DEGEN_EPS)
     ctx.filter_device(d2, sub.data_ptr(), csub.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(csub[:, b:b + a1 - a0], out[:, a0:a1])
-    # and the oracle agrees on 3 full-width rows of it
-    R = 3
+    # and the oracle agrees on R full-width rows of it
     host = sub[:, :2 * b + R].cpu().numpy()
     want = oracle.filter_pass(host, oracle.make_desc(W, 2 * b + R, S, box=7, row_begin=b, row_end=b + R,
                                                      policy=oracle.DEGEN_EPS), debug=False)["colour"][:, b:b + R]
     got = out[:, a0:a0 + R].cpu().numpy()
     assert rel_l2(got, want) <= REL_L2_BAR
-    assert rel_l2(got, host[2:5, b:b + R].astype(np.float64)) > 1e-3
+    if mode == "clustered":
+        assert rel_l2(got, host[2:5, b:b + R].astype(np.float64)) > 1e-3  # the filter did something
