@@ -1357,7 +1357,7 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
     bool bad = false;
     // own samples weighted per sweep over the neighbourhood (register budget: 4 at 3 waves/SIMD; the multi-wave kernels
     // run 1-2 waves/SIMD and take 8, halving the per-sample set-up, and gather one sample slot ahead)
-    constexpr int kOwnBlock = 8;
+    constexpr int kOwnBlock = (NW == 1 && K == 13) ? 16 : 8;
     double *sRed = sMI + 16 * wv; // 16 sums of a sweep meet here (the MI values are dead; one slot set per wave)
     // NW > 1: the sweeps are dealt round-robin to the waves of the pixel
     for (int i0 = kOwnBlock * wv; i0 < ((p.stage_mask & 8) ? S : 0); i0 += kOwnBlock * NW) {
