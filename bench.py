@@ -191,7 +191,7 @@ def main():
     out["lds_atomic_roofline"] = {"bound": "lds_atomics", "achieved": incr / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
                                   "peak": lds_peak / 1e12, "unit": "T increments/s",
                                   "frac": (incr / (k_ms * 1e-3)) / lds_peak if k_ms > 0 else 0.0,
-                                  "note": "whole-kernel time in the denominator; the MI stage alone is ~40% of it (scripts/ablate.sh)"}
+                                  "note": "whole-kernel time in the denominator; the MI stage alone is ~45% of it (scripts/ablate.sh)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(torch, planes, n_own, W, S, box, args.cpu_seconds, colour)
         if not args.fast_weights:
