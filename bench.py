@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fast-weights", action="store_true", help="opt-in fp32 pair weights (RPF_FLAG_FAST_WEIGHTS)")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one GPU per rank) is the measured path; gloo lets several ranks share one GPU to "
+                         "rehearse the multi-rank code path (halo rows staged through the host)")
     return ap.parse_args()
 
 
@@ -104,11 +107,16 @@ def main():
                      % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    if args.dist_backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     W, S, box = args.width, args.spp, args.box
     H_total = args.rows_per_gpu * world
@@ -152,7 +160,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -174,7 +182,8 @@ def main():
                    "mean_nbhd": cnt.sum_nbhd / float(n_own * W), "max_nbhd": cnt.max_nbhd,
                    "beta_map": "REF_GCC11_O3", "degenerate_policy": "REF_ABORT",
                    "nonfinite_pixels": cnt.nonfinite_pixels,
-                   "parallelism": "row slabs x%d, 3-row colour halo over RCCL send/recv" % world},
+                   "parallelism": "row slabs x%d, 3-row colour halo over %s send/recv" % (
+                       world, "RCCL" if args.dist_backend == "nccl" else "gloo (rehearsal: ranks share GPUs)")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic("%dx%dx%d_box%d" % (W, args.rows_per_gpu, S, box)),
                      "kernel": "filter_pixel_kernel", "kernel_ms": k_ms, "kernel_launches_per_step": cnt.filter_kernel_launches,

@@ -37,20 +37,24 @@ def exchange_halo(t, slab, rank, world, group=None):
     n_own = slab.row1 - slab.row0
     top0 = slab.halo_top  # first owned buffer row
     ops, recvs = [], []
+    # gloo moves host memory only: device tensors are staged through the host (CPU tests, single-GPU rehearsals of the
+    # multi-rank path); nccl (= RCCL) sends device memory directly over xGMI
+    stage = t.is_cuda and dist.get_backend(group) == "gloo"
+    wire = (lambda x: x.cpu()) if stage else (lambda x: x)
     if rank > 0 and slab.halo_top > 0:
         h = slab.halo_top
-        send_up = t[:, top0:top0 + h].contiguous()          # my first h owned rows -> bottom halo of rank-1
-        recv_up = t.new_empty((t.shape[0], h) + tuple(t.shape[2:]))
+        send_up = wire(t[:, top0:top0 + h].contiguous())    # my first h owned rows -> bottom halo of rank-1
+        recv_up = wire(t.new_empty((t.shape[0], h) + tuple(t.shape[2:])))
         ops += [dist.P2POp(dist.isend, send_up, rank - 1, group), dist.P2POp(dist.irecv, recv_up, rank - 1, group)]
         recvs.append((recv_up, 0, h))
     if rank < world - 1 and slab.halo_bottom > 0:
         h = slab.halo_bottom
-        send_dn = t[:, top0 + n_own - h:top0 + n_own].contiguous()  # my last h owned rows -> top halo of rank+1
-        recv_dn = t.new_empty((t.shape[0], h) + tuple(t.shape[2:]))
+        send_dn = wire(t[:, top0 + n_own - h:top0 + n_own].contiguous())  # my last h owned rows -> top halo of rank+1
+        recv_dn = wire(t.new_empty((t.shape[0], h) + tuple(t.shape[2:])))
         ops += [dist.P2POp(dist.isend, send_dn, rank + 1, group), dist.P2POp(dist.irecv, recv_dn, rank + 1, group)]
         recvs.append((recv_dn, top0 + n_own, h))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     for buf, r0, h in recvs:
-        t[:, r0:r0 + h].copy_(buf)
+        t[:, r0:r0 + h].copy_(buf)  # (host -> device when staged)
