@@ -294,9 +294,34 @@ __device__ __forceinline__ uint32_t bin_of_sample(const uint32_t *sBinW, int c, 
 // ones when the kernel is specialised on them, else K); holes compute on a dummy value and are masked.
 // NW > 1 (several waves per pixel): the waves split the COLUMNS -- wave wv takes fp32 columns wv, wv+NW, ... of the
 // 16 and colour column wv -- and each still covers all n samples, so no bin word is shared between waves.
-template <int KD, int KW, int PACK5, int NW = 1>
+// Per-column constants of stage 3a, formed ONCE per pixel by lane c for column c (they are wave-uniform: every lane
+// forming all 19 sets was ~1000 redundant VALU instructions per pixel) and read back by broadcast:
+//   ck[0] refined 1/SD   ck[1] lo = min z   ck[2] range = max z - min z   ck[3] refined 1/range
+//   ck[4] flags: 1 SD == 0 | 2 empty z range | 4 both divisors inside the fast window
+constexpr int kColConst = 5;
+__device__ __forceinline__ void column_constants(const double *sStat, double *sCK, int c) {
+    const double Mc = sStat[c], SDc = sStat[kNDim + c];
+    const double xlo = sStat[2 * kNDim + c], xhi = sStat[3 * kNDim + c];
+    const bool sd0 = (SDc == 0.0);
+    const UDiv dsd = udiv_prepare(SDc);
+    const double lo = sd0 ? 0.0 : udiv(xlo - Mc, dsd); // min_element over z (mi.cpp:47,49)
+    const double hi = sd0 ? 0.0 : udiv(xhi - Mc, dsd); // max_element over z (mi.cpp:48,50)
+    const double range = hi - lo;
+    const bool flat = !(hi != lo);                       // mi.cpp:7 / 28 / 34
+    const UDiv drg = udiv_prepare(range);
+    const bool fast = dsd.fast && (flat || drg.fast);
+    double *ck = sCK + c * kColConst;
+    ck[0] = dsd.r; ck[1] = lo; ck[2] = range; ck[3] = drg.r;
+    ck[4] = (double)((sd0 ? 1 : 0) | (flat ? 2 : 0) | (fast ? 4 : 0));
+}
+
+// PRE (KD == 1 only: N <= 64): the lane's one sample is still in registers from stage 2 (which gathered sample `lane` of
+// the only chunk) -- no second gather; on small neighbourhoods the stage is nothing but that gather's latency.
+template <int KD, int KW, int PACK5, int NW = 1, bool PRE = false>
 __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sStat, const uint32_t *sOff, uint32_t *sBinW,
-                                           int lane, int n, int B, int wv = 0) {
+                                           int lane, int n, int B, const double *sCK, int wv = 0,
+                                           const float *pre_f = nullptr, const double *pre_d = nullptr) {
+    static_assert(!PRE || (KD == 1 && NW == 1), "PRE needs the one-chunk case");
     const double dB = (double)B;
     {
         uint32_t offk[KD];
@@ -305,18 +330,20 @@ __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sS
         // one column: z, t, bin for the lane's K samples, packed into KW words
         auto do_column = [&](int c, const double (&xv)[KD]) {
             const double Mc = sStat[c], SDc = sStat[kNDim + c];
-            const double xlo = sStat[2 * kNDim + c], xhi = sStat[3 * kNDim + c];
-            const bool sd0 = (SDc == 0.0);
-            const UDiv dsd = udiv_prepare(SDc);
-            const double lo = sd0 ? 0.0 : udiv(xlo - Mc, dsd); // min_element over z (mi.cpp:47,49)
-            const double hi = sd0 ? 0.0 : udiv(xhi - Mc, dsd); // max_element over z (mi.cpp:48,50)
-            const double range = hi - lo;
-            const bool flat = !(hi != lo);                       // mi.cpp:7 / 28 / 34
-            const UDiv drg = udiv_prepare(range);
-            const bool fast = dsd.fast && (flat || drg.fast);   // wave-uniform
+            const double *ck = sCK + c * kColConst;             // column_constants(): wave-uniform broadcast reads
+            const double lo = ck[1], range = ck[2];
+            const int flags = (int)ck[4];
+            const bool sd0 = flags & 1, flat = flags & 2, fast = flags & 4;
+            UDiv dsd, drg;
+            dsd.b = SDc; dsd.r = ck[0]; dsd.fast = true;
+            drg.b = range; drg.r = ck[3]; drg.fast = true;
             BinIds<KW, PACK5> w;
             w.clear();
-            if (fast && !sd0 && !flat) {
+            if (sd0 || flat) {
+                // SD == 0 normalises every sample to z == 0 (ops.h:48), and a column whose z range is empty bins every
+                // sample to 0 (mi.cpp:7): the cleared words are the answer -- no per-sample work (constant normals /
+                // positions inside a cluster make this the common case on path-traced buffers)
+            } else if (fast) {
                 // the common case, straight-line for all K samples of the lane (holes compute on a dummy value
                 // and are masked at the pack), so the K dependent chains interleave
 #pragma unroll
@@ -349,7 +376,20 @@ __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sS
             }
             store_bins<KD, KW, PACK5>(sBinW, c, lane, w);
         };
-        if constexpr (NW > 1) {
+        if constexpr (PRE) {
+            if (p.stage_mask & 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const double xv[1] = {(double)pre_f[i]};
+                    do_column(i < 2 ? i : i + 3, xv);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double xv[1] = {pre_d[c]};
+                    do_column(kColC + c, xv);
+                }
+            }
+        } else if constexpr (NW > 1) {
             if (p.stage_mask & 2) {
                 auto colidx = [](int i) { return i < 2 ? i : i + 3; };
                 float xb[KD];
@@ -916,6 +956,12 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
     // sum(x) chain of column `lane` and lanes 32..50 the sum(x*x) chain of column `lane-32`.
     // The per-column min / max of x ride along (order independent): z = (x-M)/SD is monotone in x, so
     // min z = z(min x) and max z = z(max x) exactly, which is all mi.cpp:47-50 needs.
+    float keepf[16];  // the lane's sample of the last chunk stage 2 gathered (N <= 64: its only sample), for stage 3a
+    double keepd[3];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) keepf[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) keepd[i] = 0.0;
     if constexpr (NW > 1) {
         // Several waves: the in-order chains cannot be split (fp64 addition is not associative), so wave 0 does nothing
         // but run them -- lanes 0..18 sum(x), lanes 32..50 sum(x*x), as in the one-wave path -- while waves 1..NW-1
@@ -1143,6 +1189,12 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
                     wsync();
                 }
             }
+            if (n <= kStageChunk) { // one chunk: vf / vd still hold the lane's sample (no later fetch overwrote them)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) keepf[q] = vf[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) keepd[q] = vd[q];
+            }
             const double sq = __shfl(acc, (lane & 31) + 32, 64);
             const double dn = (double)n;
             const double mean = acc / dn;                      // ops.h:123
@@ -1181,19 +1233,22 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
     // ---------------- stage 3a: normalise, bin ids: bins_stage() above --------------------------
     const int B = max(1, (int)sqrt((double)n)); // mi.cpp:54
     const int kdyn = (n + kWave - 1) / kWave;   // wave-uniform: sample slots kk < kdyn exist
+    double *sCK = reinterpret_cast<double *>(sPairF); // [19][5] column constants (the pair sums are not live before 3b)
+    if (tid < kNDim) column_constants(sStat, sCK, tid);
+    bsync();
     if constexpr (K <= 8) {
         switch (kdyn) {
-        case 1: bins_stage<1, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
-        case 2: if constexpr (K >= 2) bins_stage<2, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
-        case 3: if constexpr (K >= 3) bins_stage<3, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
-        case 4: if constexpr (K >= 4) bins_stage<4, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
-        case 5: if constexpr (K >= 5) bins_stage<5, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
-        case 6: if constexpr (K >= 6) bins_stage<6, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
-        case 7: if constexpr (K >= 7) bins_stage<7, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
-        default: if constexpr (K >= 8) bins_stage<8, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B); break;
+        case 1: bins_stage<1, KW, PACK5, 1, true>(p, sStat, sOff, sBinW, lane, n, B, sCK, 0, keepf, keepd); break;
+        case 2: if constexpr (K >= 2) bins_stage<2, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B, sCK); break;
+        case 3: if constexpr (K >= 3) bins_stage<3, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B, sCK); break;
+        case 4: if constexpr (K >= 4) bins_stage<4, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B, sCK); break;
+        case 5: if constexpr (K >= 5) bins_stage<5, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B, sCK); break;
+        case 6: if constexpr (K >= 6) bins_stage<6, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B, sCK); break;
+        case 7: if constexpr (K >= 7) bins_stage<7, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B, sCK); break;
+        default: if constexpr (K >= 8) bins_stage<8, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B, sCK); break;
         }
     } else {
-        bins_stage<K, KW, PACK5, NW>(p, sStat, sOff, sBinW, lane, n, B, wv);
+        bins_stage<K, KW, PACK5, NW>(p, sStat, sOff, sBinW, lane, n, B, sCK, wv);
     }
     bsync();
     if (p.dbg.bin_hash != nullptr && tid < kNDim) { // debug only: hash in sample order j = lane + 64*slot

@@ -10,7 +10,7 @@ rpf_pkg.load()
 from raytracer_rpf_amd import feature_buffer as fb, hip
 
 W, H, S = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 16
-boxes = (7, 7, 5, 5)
+boxes = tuple(int(b) for b in os.environ.get('BOXES', '7,7,5,5').split(','))
 dev = torch.device("cuda", 0)
 planes = fb.synth_planes(W, H, S, xp=fb.torch_backend(dev), mode="clustered", sigma_f=1e-3, sigma_c=0.01).contiguous()
 col0 = planes[2:5].to(torch.float64).contiguous()
