@@ -720,6 +720,11 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
     }
 }
 
+// floor(n / d) for n * d < 2^32 with the precomputed M = floor((2^32 - 1) / d) + 1: one v_mul_hi_u32 instead of the
+// ~25-instruction sequence hipcc emits for an integer division by a run-time divisor (exact: n (M d - 2^32) < 2^32)
+__device__ __forceinline__ uint32_t div_magic(uint32_t d) { return 0xFFFFFFFFu / d + 1u; }
+__device__ __forceinline__ uint32_t div_small(uint32_t n, uint32_t M) { return M ? __umulhi(n, M) : n; } // M == 0: d == 1
+
 // XCD- and L2-aware pixel order of a slab.  Blocks with equal (blockIdx % 8) share an XCD and its 4 MiB L2: XCD r
 // filters one contiguous band of rows, and walks it in vertical strips of kStripW pixels (row by row inside a strip),
 // so the 7-row window data of the ~256 pixels in flight on the XCD (and the 6 rows shared with the next strip row)
@@ -733,19 +738,20 @@ __device__ __forceinline__ bool slab_pixel(const PassParams &p, int r, int64_t q
     const int band_rows = min(rows_band, rows_own - band_row0);
     if (band_rows <= 0) return false;
     if (ql >= (int64_t)band_rows * W) return false;
-    const int full_strips = W / kStripW;
-    const int64_t strip_px = (int64_t)kStripW * band_rows;
+    const uint32_t q = (uint32_t)ql;                       // band_rows * W < 2^32 (host-checked: W*H*S < 2^32)
+    const uint32_t full_strips = (uint32_t)W / kStripW;
+    const uint32_t strip_px = (uint32_t)kStripW * (uint32_t)band_rows;
     int yl;
-    if (ql < full_strips * strip_px) {
-        const int sidx = (int)(ql / strip_px);
-        const int rr = (int)(ql - sidx * strip_px);
-        yl = rr / kStripW;
-        x = sidx * kStripW + (rr - yl * kStripW);
+    if (q < full_strips * strip_px) {
+        const uint32_t sidx = q / strip_px;
+        const uint32_t rr = q - sidx * strip_px;
+        yl = (int)(rr / kStripW);
+        x = (int)(sidx * kStripW + (rr - (uint32_t)yl * kStripW));
     } else {
-        const int tw = W - full_strips * kStripW;
-        const int rr = (int)(ql - full_strips * strip_px);
-        yl = rr / tw;
-        x = full_strips * kStripW + (rr - yl * tw);
+        const uint32_t tw = (uint32_t)W - full_strips * kStripW;
+        const uint32_t rr = q - full_strips * strip_px;
+        yl = (int)(rr / tw);
+        x = (int)(full_strips * kStripW + (rr - (uint32_t)yl * tw));
     }
     y = p.row_begin + band_row0 + yl;
     return true;
@@ -813,6 +819,7 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
     const int ncells = (x1 - x0 + 1) * nyv;
     const int centre_rank = (x - x0) * nyv + (y - y0);
     const int ncand = (ncells - 1) * S;
+    const uint32_t magic_S = div_magic((uint32_t)S), magic_ny = div_magic((uint32_t)nyv); // qq < 4096, S, nyv <= 64
 
     for (int s = tid; s < S; s += kThreads) sOff[s] = (uint32_t)(pix * S + s); // own samples first
 
@@ -830,10 +837,10 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
             lim12[k] = p.pstd[(uint64_t)k * HW + pix] * 3.0; // multiplyArray(std, 3), rpf.cpp:579
         }
         auto cand_off = [&](int qq) -> uint32_t {
-            int cell = qq / S;
+            int cell = (int)div_small((uint32_t)qq, magic_S);
             const int s = qq - cell * S;
             if (cell >= centre_rank) ++cell;          // rpf.cpp:565: skip the centre pixel
-            const int ix = cell / nyv;                 // xn outer ascending (rpf.cpp:562)
+            const int ix = (int)div_small((uint32_t)cell, magic_ny); // xn outer ascending (rpf.cpp:562)
             const int iy = cell - ix * nyv;            // yn inner ascending (rpf.cpp:563)
             return (uint32_t)(((uint64_t)(y0 + iy) * W + (x0 + ix)) * S + s);
         };
@@ -893,10 +900,10 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
         }
         // candidate -> plane offset of its sample, in the reference's visiting order
         auto cand_off = [&](int qq) -> uint32_t {
-            int cell = qq / S;
+            int cell = (int)div_small((uint32_t)qq, magic_S);
             const int s = qq - cell * S;
             if (cell >= centre_rank) ++cell;          // rpf.cpp:565: skip the centre pixel
-            const int ix = cell / nyv;                 // xn outer ascending (rpf.cpp:562)
+            const int ix = (int)div_small((uint32_t)cell, magic_ny); // xn outer ascending (rpf.cpp:562)
             const int iy = cell - ix * nyv;            // yn inner ascending (rpf.cpp:563)
             return (uint32_t)(((uint64_t)(y0 + iy) * W + (x0 + ix)) * S + s);
         };
@@ -1576,6 +1583,7 @@ __global__ __launch_bounds__(256) void nbhd_count_kernel(PassParams p) {
     const int nyv = y1 - y0 + 1;
     const int centre_rank = (x - x0) * nyv + (y - y0);
     const int ncand = ((x1 - x0 + 1) * nyv - 1) * S;
+    const uint32_t magic_S = div_magic((uint32_t)S), magic_ny = div_magic((uint32_t)nyv);
     double m12[kNFeat], lim12[kNFeat];
 #pragma unroll
     for (int k = 0; k < kNFeat; ++k) {
@@ -1586,10 +1594,10 @@ __global__ __launch_bounds__(256) void nbhd_count_kernel(PassParams p) {
     float fb[kPF1][kNFeat];
     auto issue1 = [&](int qq, float (&f)[kNFeat]) {
         if (qq < ncand) {
-            int cell = qq / S;
+            int cell = (int)div_small((uint32_t)qq, magic_S);
             const int s = qq - cell * S;
             if (cell >= centre_rank) ++cell;          // rpf.cpp:565
-            const int ix = cell / nyv, iy = cell - ix * nyv;
+            const int ix = (int)div_small((uint32_t)cell, magic_ny), iy = cell - ix * nyv;
             const uint32_t off = (uint32_t)(((uint64_t)(y0 + iy) * W + (x0 + ix)) * S + s);
 #pragma unroll
             for (int k = 0; k < kNFeat; ++k) f[k] = p.planes[(uint64_t)(kColF + k) * p.plane_stride + off];
