@@ -211,7 +211,7 @@ def test_feature_images_bit_exact(ctx, hipmod, oracle):
 
 
 @pytest.mark.parametrize("W,H,S,box", [(10, 8, 64, 7), (14, 10, 8, 9), (12, 9, 2, 7), (21, 6, 8, 7), (13, 9, 32, 7),
-                                       (9, 8, 20, 9), (20, 18, 8, 17), (16, 12, 4, 11)])
+                                       (9, 8, 20, 9), (20, 18, 8, 17), (16, 12, 4, 11), (12, 9, 1, 7), (11, 7, 3, 5)])
 def test_more_shapes_vs_oracle(ctx, hipmod, oracle, W, H, S, box):
     """the 49-samples-per-lane kernel (64 spp), a 9x9 box, 2 spp (B tiny: replicated-histogram path), a frame
     whose width is not a multiple of anything"""
