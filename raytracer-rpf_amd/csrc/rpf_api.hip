@@ -37,6 +37,7 @@ struct rpf_ctx {
     unsigned long long *d_nred = nullptr;                  // [0] sum N [1] max N
     uint32_t *d_lists = nullptr; size_t cap_lists = 0;     // size binning: [7][H*W] pixel lists
     uint32_t *d_class_counts = nullptr;                    // [7]
+    uint64_t *d_masks = nullptr; size_t cap_masks = 0;     // size binning: stage-1b acceptance masks [H*W][stride]
     // debug planes
     void *d_dbg[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_dbg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -171,14 +172,20 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p, hipStream_t s, i
     int32_t st;
     if ((st = ensure(ctx, ctx->d_lists, ctx->cap_lists, (size_t)kNumClasses * HW * sizeof(uint32_t)))) return st;
     HIP_TRY(hipMemsetAsync(ctx->d_class_counts, 0, kNumClasses * sizeof(uint32_t), s));
-    HIP_TRY(launch_nbhd_count(p, s));
-    HIP_TRY(launch_classify(p, ctx->d_lists, ctx->d_class_counts, s));
+    // the count pass keeps its acceptance masks (one u64 per 64 candidates) so the filter kernels only rebuild the list
+    PassParams pc = p;
+    pc.mask_stride = (uint32_t)(((int64_t)(p.box * p.box - 1) * p.S + 63) / 64);
+    if (pc.mask_stride == 0) pc.mask_stride = 1;
+    if ((st = ensure(ctx, ctx->d_masks, ctx->cap_masks, HW * pc.mask_stride * sizeof(uint64_t)))) return st;
+    pc.masks = ctx->d_masks;
+    HIP_TRY(launch_nbhd_count(pc, s));
+    HIP_TRY(launch_classify(pc, ctx->d_lists, ctx->d_class_counts, s));
     uint32_t counts[kNumClasses];
     HIP_TRY(hipMemcpyAsync(counts, ctx->d_class_counts, sizeof(counts), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (int c = 0; c < kNumClasses; ++c) {
         if (counts[c] == 0) continue;
-        PassParams q = p;
+        PassParams q = pc;
         q.nmax = std::min(p.nmax, class_capacity(c));
         q.bmax = std::max(1, (int)std::sqrt((double)q.nmax));
         q.pix_list = ctx->d_lists + (size_t)c * HW;
@@ -438,7 +445,7 @@ void rpf_destroy(rpf_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *bufs[] = {ctx->d_planes, ctx->d_rayw, ctx->d_colA, ctx->d_colB, ctx->d_pmean, ctx->d_pstd, ctx->d_nbhd,
                     ctx->d_tfix, ctx->d_dfix, ctx->d_srgb, ctx->d_prgb, ctx->d_status, ctx->d_nred, ctx->d_lists,
-                    ctx->d_class_counts};
+                    ctx->d_class_counts, ctx->d_masks};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (void *b : ctx->d_dbg)

@@ -37,6 +37,8 @@ struct PassParams {
     int32_t *nbhd;         // [H*W] N per pixel (always written)
     const uint32_t *pix_list; // size-binned launch: the pixels (y*W+x) this launch filters, or null = every pixel of the slab
     uint32_t list_count;
+    uint64_t *masks;       // size-binned launch: acceptance masks of stage 1b, [H*W][mask_stride] (one per 64 candidates,
+    uint32_t mask_stride;  //   written by nbhd_count_kernel, re-used by the filter kernels), or null
     int32_t *status;       // [0] count of NaN pixels, [1] lowest bad pixel index (atomicMin)
     rpf_debug dbg;         // device pointers, any may be null
 };

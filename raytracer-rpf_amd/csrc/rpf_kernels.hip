@@ -830,6 +830,8 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
         // over <= 64 block counts, done by every wave for itself) and appends, so the list order is the reference's.
         uint64_t *sMask = reinterpret_cast<uint64_t *>(sHist0);
         const int nblk = (ncand + kWave - 1) / kWave; // <= 64 (host-checked: nmax <= 4096)
+        const bool have_masks = p.masks != nullptr;   // size-binned launch: nbhd_count_kernel already ran the test
+        if (have_masks && tid < nblk) sMask[tid] = p.masks[pix * p.mask_stride + tid];
         double m12[kNFeat], lim12[kNFeat];
 #pragma unroll
         for (int k = 0; k < kNFeat; ++k) {
@@ -855,9 +857,10 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
             }
         };
 #pragma unroll
-        for (int u = 0; u < kPF1; ++u) issue1(wv + NW * u, fb[u]);
+        for (int u = 0; u < kPF1; ++u)
+            if (!have_masks) issue1(wv + NW * u, fb[u]);
 #pragma unroll 1
-        for (int t0 = 0; wv + NW * t0 < nblk; t0 += kPF1) {
+        for (int t0 = 0; !have_masks && wv + NW * t0 < nblk; t0 += kPF1) {
 #pragma unroll
             for (int u = 0; u < kPF1; ++u) {
                 const int blk = wv + NW * (t0 + u);
@@ -891,6 +894,25 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
             if (((mask >> lane) & 1ull) && at < p.nmax) sOff[at] = cand_off(blk * kWave + lane);
         }
         n = S + __shfl(incl, kWave - 1, kWave);
+    } else if (p.masks != nullptr) {
+        // size-binned launch: nbhd_count_kernel already ran the 3-sigma test and left one acceptance mask per 64
+        // candidates; only the list is rebuilt here (wave-uniform mask loads, no feature gathers)
+        const uint64_t *pm = p.masks + pix * p.mask_stride;
+#pragma unroll 1
+        for (int qb = 0; qb < ncand; qb += kWave) {
+            const unsigned long long mask = pm[qb >> 6];
+            const int at = n + __popcll(mask & ((1ull << lane) - 1ull));
+            if (((mask >> lane) & 1ull) && at < p.nmax) {
+                const int qq = qb + lane;
+                int cell = (int)div_small((uint32_t)qq, magic_S);
+                const int s = qq - cell * S;
+                if (cell >= centre_rank) ++cell;          // rpf.cpp:565: skip the centre pixel
+                const int ix = (int)div_small((uint32_t)cell, magic_ny); // xn outer ascending (rpf.cpp:562)
+                const int iy = cell - ix * nyv;            // yn inner ascending (rpf.cpp:563)
+                sOff[at] = (uint32_t)(((uint64_t)(y0 + iy) * W + (x0 + ix)) * S + s);
+            }
+            n += __popcll(mask);
+        }
     } else {
         double m12[kNFeat], lim12[kNFeat];
 #pragma unroll
@@ -1618,7 +1640,9 @@ __global__ __launch_bounds__(256) void nbhd_count_kernel(PassParams p) {
                     const double a = fabs((double)fb[u][k] - m12[k]);
                     if (a >= lim12[k]) pass = false;       // allLessThan (ops.h:101-104)
                 }
-                n += __popcll(__ballot(pass));
+                const unsigned long long mask = __ballot(pass);
+                if (p.masks != nullptr && lane == 0) p.masks[pix * p.mask_stride + (uint32_t)(qb >> 6)] = mask;
+                n += __popcll(mask);
                 issue1(qb + kWave * kPF1 + lane, fb[u]);
             }
         }
