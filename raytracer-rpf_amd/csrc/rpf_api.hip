@@ -38,6 +38,11 @@ struct rpf_ctx {
     uint32_t *d_lists = nullptr; size_t cap_lists = 0;     // size binning: [7][H*W] pixel lists
     uint32_t *d_class_counts = nullptr;                    // [7]
     uint64_t *d_masks = nullptr; size_t cap_masks = 0;     // size binning: stage-1b acceptance masks [H*W][stride]
+    // membership depends on the features only, so within one call a pass with the same box and rows re-uses the
+    // previous pass's masks and lists (reset at every API entry: the planes may change between calls)
+    bool bin_valid = false;
+    int bin_box = 0, bin_r0 = 0, bin_r1 = 0;
+    uint32_t bin_counts[kNumClasses] = {0, 0, 0, 0, 0, 0, 0};
     // debug planes
     void *d_dbg[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_dbg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -171,18 +176,26 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p, hipStream_t s, i
     const size_t HW = (size_t)p.W * p.H;
     int32_t st;
     if ((st = ensure(ctx, ctx->d_lists, ctx->cap_lists, (size_t)kNumClasses * HW * sizeof(uint32_t)))) return st;
-    HIP_TRY(hipMemsetAsync(ctx->d_class_counts, 0, kNumClasses * sizeof(uint32_t), s));
     // the count pass keeps its acceptance masks (one u64 per 64 candidates) so the filter kernels only rebuild the list
     PassParams pc = p;
     pc.mask_stride = (uint32_t)(((int64_t)(p.box * p.box - 1) * p.S + 63) / 64);
     if (pc.mask_stride == 0) pc.mask_stride = 1;
     if ((st = ensure(ctx, ctx->d_masks, ctx->cap_masks, HW * pc.mask_stride * sizeof(uint64_t)))) return st;
     pc.masks = ctx->d_masks;
-    HIP_TRY(launch_nbhd_count(pc, s));
-    HIP_TRY(launch_classify(pc, ctx->d_lists, ctx->d_class_counts, s));
     uint32_t counts[kNumClasses];
-    HIP_TRY(hipMemcpyAsync(counts, ctx->d_class_counts, sizeof(counts), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (ctx->bin_valid && ctx->bin_box == p.box && ctx->bin_r0 == p.row_begin && ctx->bin_r1 == p.row_end) {
+        std::memcpy(counts, ctx->bin_counts, sizeof(counts));
+    } else {
+        ctx->bin_valid = false;
+        HIP_TRY(hipMemsetAsync(ctx->d_class_counts, 0, kNumClasses * sizeof(uint32_t), s));
+        HIP_TRY(launch_nbhd_count(pc, s));
+        HIP_TRY(launch_classify(pc, ctx->d_lists, ctx->d_class_counts, s));
+        HIP_TRY(hipMemcpyAsync(counts, ctx->d_class_counts, sizeof(counts), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::memcpy(ctx->bin_counts, counts, sizeof(counts));
+        ctx->bin_box = p.box; ctx->bin_r0 = p.row_begin; ctx->bin_r1 = p.row_end;
+        ctx->bin_valid = true;
+    }
     for (int c = 0; c < kNumClasses; ++c) {
         if (counts[c] == 0) continue;
         PassParams q = pc;
@@ -201,6 +214,7 @@ int32_t run_passes(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, doubl
     const bool timing = (d->flags & RPF_FLAG_TIMING) != 0;
     const size_t ps = (size_t)d->W * d->H * d->S;
     int32_t st;
+    ctx->bin_valid = false;
     if ((st = ensure(ctx, ctx->d_colB, ctx->cap_colB, 3 * ps * sizeof(double)))) return st;
     const int32_t init_status[2] = {0, INT_MAX};
     HIP_TRY(hipMemcpyAsync(ctx->d_status, init_status, sizeof(init_status), hipMemcpyHostToDevice, s));
@@ -298,6 +312,7 @@ int32_t run_host_pipeline(rpf_ctx *ctx, const rpf_desc *d, const float *planes, 
     const size_t row = (size_t)W * S, ps = row * H;
     hipStream_t s = ctx->stream, up = ctx->s_up, down = ctx->s_down;
     int32_t st;
+    ctx->bin_valid = false;
     if ((st = ensure(ctx, ctx->d_colB, ctx->cap_colB, 3 * ps * sizeof(double)))) return st;
 
     // bands: about eight, never thinner than the widest halo of the first / last pass (or 16 rows)
@@ -641,6 +656,7 @@ int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *d, int32_t box, cons
     HIP_TRY(launch_pixel_stats(ps_.p, s));
     if (timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
     int n_launch = 0;
+    ctx->bin_valid = false;
     if ((st = launch_filter_binned(ctx, ps_.p, s, &n_launch))) return st;
     if (timing) HIP_TRY(hipEventRecord(ctx->ev[1], s));
     HIP_TRY(launch_nbhd_reduce(ctx->d_nbhd, d->W, d->row_begin, d->row_end, ctx->d_nred, s));

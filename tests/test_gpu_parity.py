@@ -148,6 +148,20 @@ def test_multi_pass_and_pixel_reduction(ctx, hipmod, oracle):
     assert cnt.samples_filtered == W * H * S * 2 and cnt.filter_kernel_launches == 2
 
 
+def test_multi_pass_with_size_binning(ctx, hipmod, oracle):
+    """16 spp (box*box*S > 512: pixels are binned by neighbourhood size); a pass with the same box re-uses the previous
+    pass's membership masks and pixel lists (membership depends on the features only)"""
+    W, H, S = 15, 11, 16
+    planes = fb.synth_planes(W, H, S, seed=12, sigma_f=1e-3, sigma_c=0.01, mode="clustered")
+    srgb, prgb, st = ctx.filter(planes, hipmod.make_desc(W, H, S, boxes=(7, 7, 5), policy=hipmod.DEGEN_EPS))
+    assert st == hipmod.OK
+    c = None
+    for box in (7, 7, 5):
+        c = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=box, policy=oracle.DEGEN_EPS), colour_in=c, debug=False)["colour"]
+    assert rel_l2(srgb.astype(np.float64), c) <= REL_L2_BAR
+    assert rel_l2(srgb.astype(np.float64), planes[2:5].astype(np.float64)) > 1e-3
+
+
 @pytest.mark.parametrize("boxes,rows", [((7,), None), ((7, 5), None), ((5, 7, 5), (6, 140)), ((7,), (20, 41))])
 def test_host_entry_band_pipeline_equals_serial(ctx, hipmod, oracle, boxes, rows):
     """rpf_filter() on page-locked buffers (rpf_host_alloc) overlaps upload / filter / download over row bands; it
