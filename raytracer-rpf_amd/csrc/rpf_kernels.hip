@@ -315,13 +315,9 @@ __device__ __forceinline__ void column_constants(const double *sStat, double *sC
     ck[4] = (double)((sd0 ? 1 : 0) | (flat ? 2 : 0) | (fast ? 4 : 0));
 }
 
-// PRE (KD == 1 only: N <= 64): the lane's one sample is still in registers from stage 2 (which gathered sample `lane` of
-// the only chunk) -- no second gather; on small neighbourhoods the stage is nothing but that gather's latency.
-template <int KD, int KW, int PACK5, int NW = 1, bool PRE = false>
+template <int KD, int KW, int PACK5, int NW = 1>
 __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sStat, const uint32_t *sOff, uint32_t *sBinW,
-                                           int lane, int n, int B, const double *sCK, int wv = 0,
-                                           const float *pre_f = nullptr, const double *pre_d = nullptr) {
-    static_assert(!PRE || (KD == 1 && NW == 1), "PRE needs the one-chunk case");
+                                           int lane, int n, int B, const double *sCK, int wv = 0) {
     const double dB = (double)B;
     {
         uint32_t offk[KD];
@@ -376,20 +372,7 @@ __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sS
             }
             store_bins<KD, KW, PACK5>(sBinW, c, lane, w);
         };
-        if constexpr (PRE) {
-            if (p.stage_mask & 2) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const double xv[1] = {(double)pre_f[i]};
-                    do_column(i < 2 ? i : i + 3, xv);
-                }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const double xv[1] = {pre_d[c]};
-                    do_column(kColC + c, xv);
-                }
-            }
-        } else if constexpr (NW > 1) {
+        if constexpr (NW > 1) {
             if (p.stage_mask & 2) {
                 auto colidx = [](int i) { return i < 2 ? i : i + 3; };
                 float xb[KD];
@@ -985,12 +968,6 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
     // sum(x) chain of column `lane` and lanes 32..50 the sum(x*x) chain of column `lane-32`.
     // The per-column min / max of x ride along (order independent): z = (x-M)/SD is monotone in x, so
     // min z = z(min x) and max z = z(max x) exactly, which is all mi.cpp:47-50 needs.
-    float keepf[16];  // the lane's sample of the last chunk stage 2 gathered (N <= 64: its only sample), for stage 3a
-    double keepd[3];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) keepf[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) keepd[i] = 0.0;
     if constexpr (NW > 1) {
         // Several waves: the in-order chains cannot be split (fp64 addition is not associative), so wave 0 does nothing
         // but run them -- lanes 0..18 sum(x), lanes 32..50 sum(x*x), as in the one-wave path -- while waves 1..NW-1
@@ -1218,12 +1195,6 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
                     wsync();
                 }
             }
-            if (n <= kStageChunk) { // one chunk: vf / vd still hold the lane's sample (no later fetch overwrote them)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) keepf[q] = vf[q];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) keepd[q] = vd[q];
-            }
             const double sq = __shfl(acc, (lane & 31) + 32, 64);
             const double dn = (double)n;
             const double mean = acc / dn;                      // ops.h:123
@@ -1267,7 +1238,7 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
     bsync();
     if constexpr (K <= 8) {
         switch (kdyn) {
-        case 1: bins_stage<1, KW, PACK5, 1, true>(p, sStat, sOff, sBinW, lane, n, B, sCK, 0, keepf, keepd); break;
+        case 1: bins_stage<1, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B, sCK); break;
         case 2: if constexpr (K >= 2) bins_stage<2, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B, sCK); break;
         case 3: if constexpr (K >= 3) bins_stage<3, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B, sCK); break;
         case 4: if constexpr (K >= 4) bins_stage<4, KW, PACK5>(p, sStat, sOff, sBinW, lane, n, B, sCK); break;
