@@ -135,7 +135,7 @@ int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const float *d_plan
         p.stage_mask = sm ? std::atoi(sm) : -1;
     }
     const int64_t nmax64 = (int64_t)box * box * d->S;
-    if (nmax64 > 49 * 64) return fail(ctx, RPF_E_UNSUPPORTED, "box*box*S > 3136: neighbourhood too large for the wave-per-pixel kernel");
+    if (nmax64 > 49 * 64) return fail(ctx, RPF_E_UNSUPPORTED, "box*box*S > 3136: neighbourhood too large for the LDS-resident kernels");
     p.nmax = (int)nmax64;
     p.bmax = (int)std::sqrt((double)p.nmax);
     if (p.bmax < 1) p.bmax = 1;

@@ -6,12 +6,14 @@
 // Kernel map (reference lines -> kernel):
 //   rpf.cpp:302-353 FillMeanAndStddev                       -> pixel_stats_kernel      (thread / pixel)
 //   rpf.cpp:556-717 gather, normalise, ComputeCFWeights,
-//                   weights, blend   + mi.cpp:5-90          -> filter_pixel_kernel     (one wave64 / pixel)
+//                   weights, blend   + mi.cpp:5-90          -> filter_pixel_kernel     (one or four wave64 / pixel)
+//   (box*box*S > 512 only) N per pixel, size classes         -> nbhd_count_kernel, classify_kernel
 //   rpf.cpp:779-794 per-pixel reduction (box r=0.5)         -> reduce_kernel
 //   rpf.cpp:37-101  visualizeSF + vis.cpp:34-51             -> feature_mean_kernel, feature_normalise_kernel
 //
-// filter_pixel_kernel: one 64-lane workgroup (= one wavefront) per pixel, 12 resident per CU (157 VGPRs, 12 KiB
-// LDS), no inter-workgroup communication; DESIGN.md section 4 walks through the stages:
+// filter_pixel_kernel<K, ., ., NW>: NW = 1 -- one 64-lane workgroup (= one wavefront) per pixel, 12 resident per CU at
+// K = 7 (160 VGPRs, 12 KiB LDS); NW = 4 (K = 25, 49) -- four waves share a large neighbourhood's LDS and split columns /
+// histogram groups / own samples.  No inter-workgroup communication; DESIGN.md section 4 walks through the stages:
 //   1b  candidates of the box window are tested 64 at a time in the reference's visiting order with their gathers
 //       three steps ahead; ballot + prefix popcount append accepted offsets to an LDS list (list order ==
 //       reference neighbourhood order)
@@ -25,7 +27,7 @@
 //   4   pair weights in z-space (A_i + B_j + u_i . z_j), fp64 (or fp32 with RPF_FLAG_FAST_WEIGHTS), LDS-free
 //       transposed-butterfly reductions (rpf_xlane.h)
 // Profiling knobs (environment, read on the host): RPF_STAGE_MASK (skip stages; results wrong), RPF_LDS_PAD
-// (lower occupancy), RPF_TABLE_IN_LDS.
+// (lower occupancy), RPF_TABLE_IN_LDS, RPF_NW (waves per pixel), RPF_BINNING (size binning on/off).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <cstdlib>
