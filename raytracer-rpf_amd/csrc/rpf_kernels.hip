@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <cstdlib>
+#include <type_traits>
 
 #include "rpf_internal.h"
 #include "rpf_xlane.h"
@@ -971,78 +972,83 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
     // The per-column min / max of x ride along (order independent): z = (x-M)/SD is monotone in x, so
     // min z = z(min x) and max z = z(max x) exactly, which is all mi.cpp:47-50 needs.
     if constexpr (NW > 1) {
-        // Several waves: the in-order chains cannot be split (fp64 addition is not associative), so wave 0 does nothing
-        // but run them -- lanes 0..18 sum(x), lanes 32..50 sum(x*x), as in the one-wave path -- while waves 1..NW-1
-        // are producers: in round r producer w gathers the 19 values of the 64 samples of chunk r*(NW-1)+w-1 (issued
-        // one round ahead), tracks the column min / max and stages the chunk as doubles [column][65] in its own LDS
-        // buffer.  Barrier A: the buffers of the round are complete; wave 0 chains through them in order while the
-        // producers' next gathers are in flight; barrier B: the buffers may be overwritten.
-        constexpr int NP = NW - 1;
+        // Several waves: the in-order chains cannot be split (fp64 addition is not associative), so two waves do nothing
+        // but run them while the others are producers: in round r producer w gathers the 19 values of the 64 samples of
+        // chunk r*NP+w (issued one round ahead), tracks the column min / max and stages the chunk as doubles
+        // [column][65] in its own LDS buffer.  Barrier A: the buffers of the round are complete; the chain waves walk
+        // them in order while the producers' next gathers are in flight; barrier B: the buffers may be overwritten.
+        // Two chain waves: wave 0 sums x, wave 1 sums x*x (lanes 0..18 each) -- a wave's own instruction stream is what
+        // bounds a chain, and one wave doing both needed a per-element select; waves 2.. are the producers.
+        constexpr int NCH = 2;
+        constexpr int NP = NW - NCH;
         constexpr int kCS = kStageChunk + 1; // doubles per staged column
         const int nrun = (p.stage_mask & 1) ? n : 0;
         const int nround = (nrun + NP * kStageChunk - 1) / (NP * kStageChunk);
         double *sMM = reinterpret_cast<double *>(sHist0); // [NP][38]: column min | max seen by each producer
-        if (wv == 0) {
-            double acc = 0.0;
-            const int myc = lane & 31;
-            const bool chain = myc < kNDim;
-            const bool is_sq = lane >= 32;
-            for (int r = 0; r < nround; ++r) {
-                lds_barrier(); // A
-                if (nrun - r * NP * kStageChunk >= NP * kStageChunk) {
-                    // full round: NP*4 batches of 16 staged values, the reads of batch t+1 issued before batch t is
-                    // summed (this wave is alone on its SIMD: nothing else hides the LDS latency)
-                    constexpr int NB = NP * (kStageChunk / 16);
-                    const double *col = sStage + (chain ? myc : 0) * kCS;
-                    double vb[2][16];
-                    auto load16 = [&](int t, double (&v)[16]) {
-                        const double *src = col + (t / 4) * (kNDim * kCS) + (t % 4) * 16;
+        double *sSq = sMM + NP * 2 * kNDim;               // [19]: wave 1's sums of squares
+        double chain_acc = 0.0;                           // chain waves: the running sum of column `lane`
+        if (wv < NCH) {
+            auto chain_loop = [&](auto sq_tag) {
+                constexpr bool SQ = decltype(sq_tag)::value;
+                double acc = 0.0;
+                const bool chain = lane < kNDim;
+                for (int r = 0; r < nround; ++r) {
+                    lds_barrier(); // A
+                    if (nrun - r * NP * kStageChunk >= NP * kStageChunk) {
+                        // full round: NP*4 batches of 16 staged values, the reads of batch t+1 issued before batch t
+                        // is summed (this wave is alone on its SIMD: nothing else hides the LDS latency)
+                        constexpr int NB = NP * (kStageChunk / 16);
+                        const double *col = sStage + (chain ? lane : 0) * kCS;
+                        double vb[2][16];
+                        auto load16 = [&](int t, double (&v)[16]) {
+                            const double *src = col + (t / 4) * (kNDim * kCS) + (t % 4) * 16;
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) v[q] = src[q];
-                    };
-                    load16(0, vb[0]);
+                            for (int q = 0; q < 16; ++q) v[q] = src[q];
+                        };
+                        load16(0, vb[0]);
 #pragma unroll
-                    for (int t = 0; t < NB; ++t) {
-                        if (t + 1 < NB) load16(t + 1, vb[(t + 1) & 1]);
-                        double (&v)[16] = vb[t & 1];
+                        for (int t = 0; t < NB; ++t) {
+                            if (t + 1 < NB) load16(t + 1, vb[(t + 1) & 1]);
+                            double (&v)[16] = vb[t & 1];
+                            if constexpr (SQ) {
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) v[q] = is_sq ? v[q] * v[q] : v[q]; // ops.h:138 multiplyArrays
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) acc = acc + v[q];                 // ops.h:121 / 138 sumArrays
-                    }
-                } else {
-#pragma unroll 1
-                    for (int w = 0; w < NP; ++w) {
-                        const int cnt = min(kStageChunk, nrun - (r * NP + w) * kStageChunk); // wave-uniform
-                        if (cnt <= 0) break;
-                        if (chain) {
-                            const double *src = sStage + w * (kNDim * kCS) + myc * kCS;
-                            int q0 = 0;
-                            for (; q0 + 16 <= cnt; q0 += 16) {
-                                double v[16];
-#pragma unroll
-                                for (int q = 0; q < 16; ++q) v[q] = src[q0 + q];
-#pragma unroll
-                                for (int q = 0; q < 16; ++q) v[q] = is_sq ? v[q] * v[q] : v[q];
-#pragma unroll
-                                for (int q = 0; q < 16; ++q) acc = acc + v[q];
+                                for (int q = 0; q < 16; ++q) v[q] = v[q] * v[q];       // ops.h:138 multiplyArrays
                             }
-                            for (int q = q0; q < cnt; ++q) { const double v = src[q]; acc = acc + (is_sq ? v * v : v); }
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) acc = acc + v[q];             // ops.h:121 / 138 sumArrays
+                        }
+                    } else {
+#pragma unroll 1
+                        for (int w = 0; w < NP; ++w) {
+                            const int cnt = min(kStageChunk, nrun - (r * NP + w) * kStageChunk); // wave-uniform
+                            if (cnt <= 0) break;
+                            if (chain) {
+                                const double *src = sStage + w * (kNDim * kCS) + lane * kCS;
+                                int q0 = 0;
+                                for (; q0 + 16 <= cnt; q0 += 16) {
+                                    double v[16];
+#pragma unroll
+                                    for (int q = 0; q < 16; ++q) v[q] = src[q0 + q];
+                                    if constexpr (SQ) {
+#pragma unroll
+                                        for (int q = 0; q < 16; ++q) v[q] = v[q] * v[q];
+                                    }
+#pragma unroll
+                                    for (int q = 0; q < 16; ++q) acc = acc + v[q];
+                                }
+                                for (int q = q0; q < cnt; ++q) { const double v = src[q]; acc = acc + (SQ ? v * v : v); }
+                            }
                         }
                     }
+                    lds_barrier(); // B
                 }
-                lds_barrier(); // B
-            }
-            const double sq = __shfl(acc, (lane & 31) + 32, 64);
-            const double dn = (double)n;
-            const double mean = acc / dn;                      // ops.h:123
-            double sd = sqrt(sq / dn - mean * mean);           // ops.h:141
-            if (p.policy == RPF_DEGEN_EPS && isnan(sd)) sd = 0.0;
-            if (lane < kNDim) {
-                sStat[lane] = mean;
-                sStat[kNDim + lane] = sd;
-                if (p.dbg.mean) p.dbg.mean[pix * kNDim + lane] = mean;
-                if (p.dbg.stddev) p.dbg.stddev[pix * kNDim + lane] = sd;
+                return acc;
+            };
+            if (wv == 0) {
+                chain_acc = chain_loop(std::false_type{});
+            } else {
+                const double sq = chain_loop(std::true_type{});
+                if (lane < kNDim) sSq[lane] = sq;
             }
         } else {
             float fmn[16], fmx[16];  // non-colour columns: 0,1 then 5..18
@@ -1051,7 +1057,7 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
             for (int i = 0; i < 16; ++i) { fmn[i] = INFINITY; fmx[i] = -INFINITY; }
 #pragma unroll
             for (int i = 0; i < 3; ++i) { cmn[i] = INFINITY; cmx[i] = -INFINITY; }
-            double *sStageP = sStage + (wv - 1) * (kNDim * kCS);
+            double *sStageP = sStage + (wv - NCH) * (kNDim * kCS);
             float vf[16];
             double vd[3];
             auto fetch = [&](int j) {
@@ -1063,9 +1069,9 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
                     for (int i = 0; i < 3; ++i) vd[i] = p.col_in[(uint64_t)i * p.plane_stride + off];
                 }
             };
-            fetch((wv - 1) * kStageChunk + lane);
+            fetch((wv - NCH) * kStageChunk + lane);
             for (int r = 0; r < nround; ++r) {
-                const int j0 = (r * NP + wv - 1) * kStageChunk;
+                const int j0 = (r * NP + wv - NCH) * kStageChunk;
                 if (j0 + lane < nrun) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -1091,7 +1097,7 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
                 lds_barrier(); // B
             }
             // this wave's min / max of x per column -> sMM[wv-1][c], sMM[wv-1][19 + c]
-            double *mm = sMM + (wv - 1) * (2 * kNDim);
+            double *mm = sMM + (wv - NCH) * (2 * kNDim);
             float a32[32];
 #pragma unroll
             for (int i = 0; i < 16; ++i) { a32[i] = fmn[i]; a32[16 + i] = -fmx[i]; }
@@ -1110,6 +1116,16 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
             }
         }
         __syncthreads();
+        if (tid < kNDim) { // wave 0 holds the sums, wave 1 left the sums of squares in LDS
+            const double dn = (double)n;
+            const double mean = chain_acc / dn;                       // ops.h:123
+            double sd = sqrt(sSq[tid] / dn - mean * mean);            // ops.h:141
+            if (p.policy == RPF_DEGEN_EPS && isnan(sd)) sd = 0.0;
+            sStat[tid] = mean;
+            sStat[kNDim + tid] = sd;
+            if (p.dbg.mean) p.dbg.mean[pix * kNDim + tid] = mean;
+            if (p.dbg.stddev) p.dbg.stddev[pix * kNDim + tid] = sd;
+        }
         if (tid < 2 * kNDim) { // min over the producers (slots 0..18), max (slots 19..37)
             double v = sMM[tid];
 #pragma unroll
@@ -1852,7 +1868,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     L.off_union = o;
     const int nw = waves_per_pixel(nmax);
     L.nw = (uint32_t)nw;
-    const uint32_t stage = nw > 1 ? align_up((uint32_t)(nw - 1) * kNDim * (kStageChunk + 1) * 8u, 16) // one chunk per producer wave
+    const uint32_t stage = nw > 1 ? align_up((uint32_t)(nw - 2) * kNDim * (kStageChunk + 1) * 8u, 16) // one chunk per producer wave
                                   : align_up(kNDim * (kStageHalf + 1) * 8, 16);
     const uint32_t bins = K <= 8 ? align_up((uint32_t)kNDim * kWave * 5u, 16)          // 5-bit words + slot-6 bytes
                                  : align_up((uint32_t)kNDim * kWave * KW * 4u, 16);     // 5- or 6-bit fields in KW words
