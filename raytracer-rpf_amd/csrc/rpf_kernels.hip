@@ -1311,7 +1311,14 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
         const double dn = (double)n;
         for (int pr = tid; pr < kNPair; pr += kThreads) {
             const int ca = c_pairs.a[pr], cb = c_pairs.b[pr];
-            const int64_t f = TNf + (int64_t)sPairF[pr] - (int64_t)sHXf[ca] - (int64_t)sHXf[cb];
+            int64_t f = TNf + (int64_t)sPairF[pr] - (int64_t)sHXf[ca] - (int64_t)sHXf[cb];
+            // Exactly independent histograms (J_ij N == hx_i hy_j on every occupied cell): the reference's terms are
+            // p log(1.0) == 0 exactly whenever its quotients are exact (always for N a power of two, e.g. N == S), and
+            // that exact zero decides 0/0 at rpf.cpp:465/470.  The table entries are rounded to 2^-44, so such a sum
+            // lands within (#terms / 2) units of zero instead of on it: snap it.  (A non-zero N*MI is >= 1/(2 N^2 E),
+            // orders of magnitude above the bound for all but contrived N > 1700 tables.)
+            const int64_t zero_band = ((int64_t)B * B + 2 * B + 1) / 2 + 1;
+            if (f <= zero_band && f >= -zero_band) f = 0;
             const double mi = ldexp((double)f, -kTFixBits) / dn;
             sMI[pr] = mi;
             if (p.dbg.mi) p.dbg.mi[pix * kNPair + pr] = mi;
