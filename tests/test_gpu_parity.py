@@ -391,3 +391,32 @@ def test_full_size_properties(ctx, hipmod, oracle, W, H, S, mode, sf, sc, R):
     assert rel_l2(got, want) <= REL_L2_BAR
     if mode == "clustered":
         assert rel_l2(got, host[2:5, b:b + R].astype(np.float64)) > 1e-3  # the filter did something
+
+
+def test_randomised_parity_sweep(ctx, hipmod, oracle):
+    """40 random configurations (scripts/fuzz_parity.py runs the same sweep at any length): shapes, 1..64 spp, boxes
+    3..11, both generators, both policies, all beta presets; REF_ABORT cases must reproduce the oracle's NaN pattern"""
+    rng = np.random.default_rng(424242)
+    for _ in range(40):
+        box = int(rng.choice([3, 5, 7, 7, 7, 9, 11]))
+        smax = max(1, 3136 // (box * box))
+        S = int(rng.choice([s for s in (1, 2, 3, 4, 5, 8, 8, 12, 16, 24, 32, 48, 64) if s <= smax]))
+        W, H = int(rng.integers(3, 26)), int(rng.integers(2, 18))
+        while W * H * S > 40000:
+            W, H = max(3, W - 2), max(2, H - 1)
+        mode = str(rng.choice(["smooth", "clustered"]))
+        sf = float(rng.choice([1e-5, 1e-3, 0.02, 0.05]))
+        policy = int(rng.choice([hipmod.DEGEN_EPS, hipmod.DEGEN_EPS, hipmod.DEGEN_REF_ABORT]))
+        beta = int(rng.integers(0, 3))
+        planes = fb.synth_planes(W, H, S, seed=int(rng.integers(0, 1 << 30)), sigma_f=sf, sigma_c=0.01, mode=mode)
+        got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, policy=policy, beta_map=beta), box=box,
+                                    allow_nonfinite=True)
+        want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=box, policy=policy, beta_map=beta))
+        tag = (W, H, S, box, mode, sf, policy, beta)
+        assert got["nonfinite_pixels"] == want["nonfinite_pixels"], tag
+        if np.isfinite(want["colour"]).all():
+            check_pass(got, want, ab_rtol=5e-3 if policy == hipmod.DEGEN_EPS else 1e-9)
+        else:
+            for k in ("nbhd_size", "member_hash", "bin_hash"):
+                assert (got[k] == want[k]).all(), (k, tag)
+            assert (np.isfinite(got["colour"]) == np.isfinite(want["colour"])).all(), tag
