@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--box", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fast-weights", action="store_true", help="opt-in fp32 pair weights (RPF_FLAG_FAST_WEIGHTS)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="rpf_set_option override (diagnostics: stage_mask, binning, waves_per_pixel, table_in_lds, lds_pad)")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank) is the measured path; gloo lets several ranks share one GPU to "
@@ -132,6 +134,9 @@ def main():
     colour0 = planes[2:5].to(torch.float64).contiguous()
     colour = colour0.clone()
     ctx = hip.Context(local_rank)
+    for kv in args.option:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     flags = hip.FLAG_TIMING | (hip.FLAG_FAST_WEIGHTS if args.fast_weights else 0)
     desc = hip.make_desc(W, H_buf, S, boxes=(box,), row_begin=row_begin, row_end=row_end, flags=flags)
     stream = torch.cuda.current_stream().cuda_stream

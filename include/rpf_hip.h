@@ -18,9 +18,9 @@
  * device, exactly as the reference carries them in SampleData doubles.
  *
  * Threading: one caller thread per rpf_ctx at a time; distinct contexts are independent.
- * Multi-GPU: one context per device (one process per GPU); a context filters a ROW SLAB
- * [row_begin,row_end) of a buffer that also holds the halo rows it needs (see raytracer-rpf_amd/slabs.py
- * for the RCCL neighbour exchange).
+ * Multi-GPU: one context per device; a context filters a ROW SLAB [row_begin,row_end) of a buffer that also holds
+ * the halo rows it needs.  A strict sub-slab is filtered ONE pass per call (n_box == 1) with a colour-halo exchange
+ * between passes: raytracer-rpf_amd/slabs.py does that across processes (RCCL send/recv).
  */
 #ifndef RPF_HIP_H
 #define RPF_HIP_H
@@ -80,7 +80,7 @@ typedef struct rpf_desc {
     int32_t S;                         /* samples per pixel, identical for every pixel              */
     int32_t row_begin;                 /* first row to filter                                       */
     int32_t row_end;                   /* one past the last row to filter                           */
-    int32_t n_box;                     /* number of passes                                          */
+    int32_t n_box;                     /* number of passes (> 1 only when the slab is the whole buffer) */
     int32_t box_sizes[RPF_MAX_BOXES];  /* odd box sizes, one per pass (reference: {7}, rpf.cpp:767)  */
     int32_t beta_map;                  /* rpf_beta_map                                              */
     int32_t degenerate_policy;         /* rpf_degenerate_policy                                     */
@@ -114,6 +114,7 @@ typedef struct rpf_counters {
     float h2d_ms;               /* rpf_filter(): host->HBM marshalling, wall clock                  */
     float d2h_ms;               /* rpf_filter(): HBM->host                                          */
     int32_t filter_kernel_launches;
+    int32_t options_active;     /* 1 when any rpf_set_option override was in force (diagnostic runs)   */
 } rpf_counters;
 
 const char *rpf_version(void);
@@ -134,6 +135,25 @@ const char *rpf_last_error(const rpf_ctx *ctx);
  */
 int32_t rpf_filter(rpf_ctx *ctx, const rpf_desc *desc, const float *planes, const float *ray_weight,
                    float *sample_rgb_out, float *pixel_rgb_out);
+
+/* rpf_filter() with the sample colours carried as doubles across the boundary, as the reference carries them in
+ * SampleData (sd.h:205-208 getColorI / setColorI; the film that one ApplyRPFFilter call leaves is the input of the next,
+ * rpf.cpp:732, 767-775).  A caller that keeps the reference's call shape -- one ApplyRPFFilter(film, tile, box) per box
+ * size -- uses this so that no colour is rounded to fp32 between passes:
+ *   colour64_in   host, 3 fp64 planes [3][H][W][S], or NULL (= planes 2..4 of `planes`)
+ *   colour64_out  host, 3 fp64 planes of filtered colours, or NULL
+ * With either pointer set the call runs upload, passes, download one after the other (no row-band overlap). */
+int32_t rpf_filter_ex(rpf_ctx *ctx, const rpf_desc *desc, const float *planes, const double *colour64_in,
+                      const float *ray_weight, float *sample_rgb_out, float *pixel_rgb_out, double *colour64_out);
+
+/* Per-context tuning / diagnostic overrides (nothing in the library reads the environment).  Names:
+ *   "stage_mask"       -1 = all stages (default); other values SKIP stages for timing ablations: results are WRONG
+ *   "binning"          -1 auto (size-binned launches when box*box*S > 512), 0 off, 1 on
+ *   "waves_per_pixel"  0 auto, 1, 4 (4 needs box*box*S > 832)
+ *   "table_in_lds"     -1 auto, 0, 1
+ *   "lds_pad"          extra LDS bytes per workgroup (lowers occupancy)
+ * rpf_counters.options_active tells whether a result was produced under any override. */
+int32_t rpf_set_option(rpf_ctx *ctx, const char *name, int64_t value);
 
 /* Page-locked host memory for the buffers handed to rpf_filter(): a feature producer that writes its samples straight
  * into such planes (instead of the reference's heap SamplingFilm, sample_film.cpp:6-43) gets full-rate DMA and real

@@ -69,6 +69,7 @@ def lib():
         L.rpf_oracle_pixel_mean.argtypes = [C.POINTER(Desc), C.c_void_p, C.c_void_p, C.c_void_p]
         L.rpf_oracle_pair_table.argtypes = [C.c_void_p, C.c_void_p]
         L.rpf_oracle_feature_images.argtypes = [C.POINTER(Desc), C.c_void_p, C.c_void_p]
+        L.rpf_oracle_weighted_sqdist.argtypes = [C.c_void_p] * 5
         _lib = L
     return _lib
 
@@ -148,6 +149,25 @@ def mean_std(rows):
     m, s = np.empty(nc), np.empty(nc)
     lib().rpf_oracle_mean_std(_p(rows), n, nc, _p(m), _p(s))
     return m, s
+
+
+def weighted_sqdist(zi, zj, alpha, beta):
+    """stage 4a's (position, colour, feature) weighted squared distances of two normalised 19-vectors"""
+    zi, zj, alpha, beta = _f64(zi), _f64(zj), _f64(alpha), _f64(beta)
+    out = np.empty(3)
+    lib().rpf_oracle_weighted_sqdist(_p(zi), _p(zj), _p(alpha), _p(beta), _p(out))
+    return out
+
+
+def ref_weighted_sqdist(zi, zj, alpha, beta):
+    """the same three sums composed from the compiled ops.h templates as rpf.cpp:646-660 composes them"""
+    zi, zj, alpha, beta = _f64(zi), _f64(zj), _f64(alpha), _f64(beta)
+    R = ref()
+    p_i, p_j = np.ascontiguousarray(zi[0:2]), np.ascontiguousarray(zj[0:2])
+    c_i, c_j = np.ascontiguousarray(zi[2:5]), np.ascontiguousarray(zj[2:5])
+    f_i, f_j = np.ascontiguousarray(zi[7:19]), np.ascontiguousarray(zj[7:19])
+    return np.array([R.ref_weighted_sqdist_2(_p(p_i), _p(p_j)), R.ref_weighted_sqdist_3(_p(c_i), _p(c_j), _p(alpha)),
+                     R.ref_weighted_sqdist_12(_p(f_i), _p(f_j), _p(beta))])
 
 
 def pair_table():

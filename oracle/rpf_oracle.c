@@ -58,8 +58,25 @@ static void min_max(const double *v, int n, double *lo, double *hi) {
     *hi = mx;
 }
 
-/* mi.cpp:45-90 with the default bins (= -1) */
-static double mi_scratch(const double *x, const double *y, int n, int *hx, int *hy, int *joint) {
+/* T[k] = round(k ln k * 2^44), k = 0..nmax: the table of the EPS residue contract below (the product computes the
+ * same table on the host, csrc/rpf_api.hip ensure_tables) */
+static int64_t *tfix_table(int nmax) {
+    int64_t *t = (int64_t *)malloc(sizeof(int64_t) * ((size_t)nmax + 1));
+    t[0] = 0;
+    for (int k = 1; k <= nmax; ++k) t[k] = (int64_t)llroundl(ldexpl((long double)k * logl((long double)k), 44));
+    return t;
+}
+
+/* mi.cpp:45-90 with the default bins (= -1).
+ * tfix == NULL: the reference, statement by statement (REF_ABORT policy, rpf_oracle_mi, every pin).
+ * tfix != NULL (EPS policy only -- part of that DOCUMENTED DEVIATION, not of the reference): the EPS residue
+ * contract.  N*MI = T[N] + sum T[J_ij] - sum T[hx_i] - sum T[hy_j] with T[k] = k ln k; for a table whose cells are
+ * exactly independent that expression is 0, and what mi.cpp returns for it is pure rounding residue (+-1e-16, or an
+ * exact 0 when N is a power of two).  Divided by (residue + eps) in rpf.cpp:464-470 such residue turns into an
+ * arbitrary weight, so under EPS it is DEFINED away: when the integer sum of the 2^-44 fixed-point table lies
+ * inside the table's own rounding band, (B*B + 2B + 1)/2 + 1 units, MI is exactly 0.  Both sides (this oracle and the
+ * HIP kernel) apply the same integer rule, so the EPS weights agree to rounding. */
+static double mi_scratch(const double *x, const double *y, int n, int *hx, int *hy, int *joint, const int64_t *tfix) {
     double minX, maxX, minY, maxY;
     min_max(x, n, &minX, &maxX);
     min_max(y, n, &minY, &maxY);
@@ -77,6 +94,13 @@ static double mi_scratch(const double *x, const double *y, int n, int *hx, int *
         if (maxX != minX) bx = bin_of(x[i], minX, maxX, bins);
         if (maxY != minY) by = bin_of(y[i], minY, maxY, bins);
         joint[bx * bins + by]++;
+    }
+    if (tfix) {
+        int64_t f = tfix[n];
+        for (int i = 0; i < bins; ++i) f -= tfix[hx[i]] + tfix[hy[i]];
+        for (int i = 0; i < bins * bins; ++i) f += tfix[joint[i]];
+        const int64_t band = ((int64_t)bins * bins + 2 * bins + 1) / 2 + 1;
+        if (f <= band && f >= -band) return 0.0;
     }
     double total = (double)n; /* mi.cpp:66 */
     double mi = 0.0;
@@ -96,7 +120,7 @@ double rpf_oracle_mi(const double *x, const double *y, int32_t n) {
     int bins = (int)sqrt((double)n);
     if (bins < 1) bins = 1;
     int *buf = (int *)malloc(sizeof(int) * (size_t)(2 * bins + bins * bins));
-    double r = mi_scratch(x, y, n, buf, buf + bins, buf + 2 * bins);
+    double r = mi_scratch(x, y, n, buf, buf + bins, buf + 2 * bins, NULL);
     free(buf);
     return r;
 }
@@ -152,6 +176,7 @@ void rpf_oracle_pixel_stats(const rpf_oracle_desc *d, const float *planes, doubl
 typedef struct {
     double *col[RPF_O_NDIM]; /* 19 column vectors of length n (rpf.cpp:381-412) */
     int *hx, *hy, *joint;
+    const int64_t *tfix;     /* EPS residue contract table (mi_scratch), NULL under REF_ABORT */
 } cf_scratch;
 
 static void cf_weights_core(const double *z, int n, int beta_map, int policy, double eps, cf_scratch *sc,
@@ -168,13 +193,13 @@ static void cf_weights_core(const double *z, int n, int beta_map, int policy, do
     double v;
     for (int i = 0; i < 12; ++i) { /* rpf.cpp:416-427 */
         for (int j = 0; j < 2; ++j) {
-            v = mi_scratch(sc->col[C_F0 + i], sc->col[C_R0 + j], n, sc->hx, sc->hy, sc->joint);
+            v = mi_scratch(sc->col[C_F0 + i], sc->col[C_R0 + j], n, sc->hx, sc->hy, sc->joint, policy == RPF_O_DEGEN_EPS ? sc->tfix : NULL);
             D_r_fk[i] += v;
             if (mi96) mi96[p] = v;
             ++p;
         }
         for (int j = 0; j < 2; ++j) {
-            v = mi_scratch(sc->col[C_F0 + i], sc->col[C_P0 + j], n, sc->hx, sc->hy, sc->joint);
+            v = mi_scratch(sc->col[C_F0 + i], sc->col[C_P0 + j], n, sc->hx, sc->hy, sc->joint, policy == RPF_O_DEGEN_EPS ? sc->tfix : NULL);
             D_p_fk[i] += v;
             if (mi96) mi96[p] = v;
             ++p;
@@ -182,19 +207,19 @@ static void cf_weights_core(const double *z, int n, int beta_map, int policy, do
     }
     for (int i = 0; i < 3; ++i) { /* rpf.cpp:429-442 */
         for (int j = 0; j < 2; ++j) {
-            v = mi_scratch(sc->col[C_C0 + i], sc->col[C_R0 + j], n, sc->hx, sc->hy, sc->joint);
+            v = mi_scratch(sc->col[C_C0 + i], sc->col[C_R0 + j], n, sc->hx, sc->hy, sc->joint, policy == RPF_O_DEGEN_EPS ? sc->tfix : NULL);
             D_r_ck[i] += v;
             if (mi96) mi96[p] = v;
             ++p;
         }
         for (int j = 0; j < 2; ++j) {
-            v = mi_scratch(sc->col[C_C0 + i], sc->col[C_P0 + j], n, sc->hx, sc->hy, sc->joint);
+            v = mi_scratch(sc->col[C_C0 + i], sc->col[C_P0 + j], n, sc->hx, sc->hy, sc->joint, policy == RPF_O_DEGEN_EPS ? sc->tfix : NULL);
             D_p_ck[i] += v;
             if (mi96) mi96[p] = v;
             ++p;
         }
         for (int j = 0; j < 12; ++j) {
-            v = mi_scratch(sc->col[C_C0 + i], sc->col[C_F0 + j], n, sc->hx, sc->hy, sc->joint);
+            v = mi_scratch(sc->col[C_C0 + i], sc->col[C_F0 + j], n, sc->hx, sc->hy, sc->joint, policy == RPF_O_DEGEN_EPS ? sc->tfix : NULL);
             D_f_ck[i] += v;
             D_cf_k[j] += v;
             if (mi96) mi96[p] = v;
@@ -234,6 +259,7 @@ static void cf_scratch_alloc(cf_scratch *sc, int nmax) {
     sc->hx = (int *)malloc(sizeof(int) * (size_t)(2 * bins + bins * bins));
     sc->hy = sc->hx + bins;
     sc->joint = sc->hy + bins;
+    sc->tfix = NULL;
 }
 static void cf_scratch_free(cf_scratch *sc) {
     for (int c = 0; c < RPF_O_NDIM; ++c) free(sc->col[c]);
@@ -244,8 +270,27 @@ void rpf_oracle_cf_weights(const double *z, int32_t n, int32_t beta_map, int32_t
                            double alpha[3], double beta[12], double *wrc, double *mi96) {
     cf_scratch sc;
     cf_scratch_alloc(&sc, n);
+    int64_t *tf = policy == RPF_O_DEGEN_EPS ? tfix_table(n) : NULL;
+    sc.tfix = tf;
     cf_weights_core(z, n, beta_map, policy, eps, &sc, alpha, beta, wrc, mi96);
     cf_scratch_free(&sc);
+    free(tf);
+}
+
+/* rpf.cpp:646-660: the three weighted squared distances of a pair of NORMALISED samples (19 columns each):
+ * sumArray(squareArray(subtractArrays(P_i, P_j))), sumArray(multiplyArrays(squareArray(subtractArrays(C_i, C_j)), Alpha)),
+ * sumArray(multiplyArrays(squareArray(subtractArrays(F_i, F_j)), Beta)) -- ops.h:17-97, sequential sums from 0 */
+static void weighted_sqdist(const double *si, const double *sj, const double *alpha, const double *beta, double *sp_,
+                            double *sc_, double *sf_) {
+    double sp = 0, scol = 0, sf = 0;
+    for (int k = 0; k < 2; ++k) { double t = si[C_P0 + k] - sj[C_P0 + k]; sp += t * t; }
+    for (int k = 0; k < 3; ++k) { double t = si[C_C0 + k] - sj[C_C0 + k]; scol += (t * t) * alpha[k]; }
+    for (int k = 0; k < 12; ++k) { double t = si[C_F0 + k] - sj[C_F0 + k]; sf += (t * t) * beta[k]; }
+    *sp_ = sp; *sc_ = scol; *sf_ = sf;
+}
+void rpf_oracle_weighted_sqdist(const double *zi, const double *zj, const double alpha[3], const double beta[12],
+                                double out3[3]) {
+    weighted_sqdist(zi, zj, alpha, beta, &out3[0], &out3[1], &out3[2]);
 }
 
 static uint32_t fnv1a_u32(uint32_t h, uint32_t v) {
@@ -278,6 +323,7 @@ void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const
 
     int32_t first_bad = INT_MAX, max_n = 0;
     int64_t n_bad = 0, sum_n = 0;
+    int64_t *tfix = d->degenerate_policy == RPF_O_DEGEN_EPS ? tfix_table(nmax) : NULL;
 
 #ifdef _OPENMP
     if (d->n_threads > 0) omp_set_num_threads(d->n_threads);
@@ -291,6 +337,7 @@ void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const
         uint32_t *code = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nmax);
         cf_scratch sc;
         cf_scratch_alloc(&sc, nmax);
+        sc.tfix = tfix;
         int32_t t_first = INT_MAX, t_max = 0;
         int64_t t_bad = 0, t_sum = 0;
 
@@ -387,10 +434,8 @@ void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const
                     const double *si = zo + i * RPF_O_NDIM;
                     for (int j = 0; j < n; ++j) {
                         const double *sj = z + (size_t)j * RPF_O_NDIM;
-                        double sp = 0, scol = 0, sf = 0;
-                        for (int k = 0; k < 2; ++k) { double t = si[C_P0 + k] - sj[C_P0 + k]; sp += t * t; }
-                        for (int k = 0; k < 3; ++k) { double t = si[C_C0 + k] - sj[C_C0 + k]; scol += (t * t) * alpha[k]; }
-                        for (int k = 0; k < 12; ++k) { double t = si[C_F0 + k] - sj[C_F0 + k]; sf += (t * t) * beta[k]; }
+                        double sp, scol, sf;
+                        weighted_sqdist(si, sj, alpha, beta, &sp, &scol, &sf);
                         wm[(size_t)i * n + j] = exp(-sp / (2 * sigma_p_squared)) * exp(-scol / (2 * sigma_c_squared)) *
                                                 exp(-sf / (2 * sigma_f_squared)); /* rpf.cpp:667-670 */
                     }
@@ -431,6 +476,7 @@ void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const
     }
     free(pmean);
     free(pstd);
+    free(tfix);
     if (res) {
         res->nonfinite_pixels = n_bad;
         res->first_bad_pixel = n_bad ? first_bad : -1;

@@ -50,7 +50,9 @@ enum {
 
 enum {
     RPF_O_DEGEN_REF_ABORT = 0, /* IEEE propagation; first non-finite pixel reported (rpf.cpp:702-705) */
-    RPF_O_DEGEN_EPS = 1        /* documented deviation: eps in the three denominators, var clamped >= 0 */
+    RPF_O_DEGEN_EPS = 1        /* documented deviation: eps in the three denominators, var clamped >= 0, and the
+                                  residue contract: an MI whose 2^-44 fixed-point integer form lies inside the
+                                  table's rounding band is exactly 0 (rpf_oracle.c, mi_scratch) */
 };
 
 typedef struct rpf_oracle_desc {
@@ -103,6 +105,12 @@ void rpf_oracle_pixel_stats(const rpf_oracle_desc *d, const float *planes, doubl
 /* A5 on an already normalised neighbourhood: z is n x 19 row-major. mi96 may be NULL. */
 void rpf_oracle_cf_weights(const double *z, int32_t n, int32_t beta_map, int32_t policy, double eps,
                            double alpha[3], double beta[12], double *wrc, double *mi96);
+
+/* stage 4a's three weighted squared distances of two NORMALISED 19-vectors (rpf.cpp:646-660): out3 = {position,
+ * colour (x alpha), feature (x beta)} -- exactly the function the filter pass calls; pinned against the compiled
+ * ops.h composition in tests/test_oracle.py. */
+void rpf_oracle_weighted_sqdist(const double *zi, const double *zj, const double alpha[3], const double beta[12],
+                                double out3[3]);
 
 /* One filter pass (A1..A8) for one box size.
  *   planes     19 fp32 planes (colour planes 2..4 used unless colour_in != NULL)

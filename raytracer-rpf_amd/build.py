@@ -9,7 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB = os.path.join(_HERE, "lib", "librpf_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("rpf_kernels.hip", "rpf_api.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "rpf_internal.h"), os.path.join(_ROOT, "include", "rpf_hip.h")]
+HEADERS = [os.path.join(_HERE, "csrc", "rpf_internal.h"), os.path.join(_HERE, "csrc", "rpf_xlane.h"),
+           os.path.join(_ROOT, "include", "rpf_hip.h")]
 
 
 def hipcc_path():

@@ -51,6 +51,7 @@ struct rpf_ctx {
     hipStream_t s_up = nullptr, s_down = nullptr;
     std::vector<hipEvent_t> band_ev; // no-timing events, two per band
     rpf_counters counters{};
+    Tuning tun;                      // rpf_set_option
 };
 
 namespace {
@@ -92,6 +93,14 @@ int32_t validate(rpf_ctx *ctx, const rpf_desc *d, bool need_boxes) {
         return fail(ctx, RPF_E_BADARG, "unknown degenerate_policy");
     if (need_boxes) {
         if (d->n_box < 1 || d->n_box > RPF_MAX_BOXES) return fail(ctx, RPF_E_BADARG, "n_box must be 1..8");
+        // The reference filters the WHOLE film in every pass (rpf.cpp:732 swaps the full film), so pass i+1 reads
+        // filtered colours in every window row.  A strict sub-slab only filters its own rows: its halo rows would stay
+        // unfiltered and the owned rows next to them would silently differ from the full-frame result.  Sub-slabs are
+        // therefore driven one pass per call, with a colour-halo exchange in between (rpf_filter_multi does exactly
+        // that inside one process; slabs.py across processes).
+        if (d->n_box > 1 && (d->row_begin != 0 || d->row_end != d->H))
+            return fail(ctx, RPF_E_BADARG, "n_box > 1 needs row_begin == 0 and row_end == H: a sub-slab must be filtered "
+                                           "one pass per call with a colour-halo exchange in between (or rpf_filter_multi)");
         for (int i = 0; i < d->n_box; ++i)
             if (d->box_sizes[i] < 1 || (d->box_sizes[i] & 1) == 0)
                 return fail(ctx, RPF_E_BADARG, "box sizes must be odd and positive (rpf.cpp:561)");
@@ -130,10 +139,7 @@ int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const float *d_plan
     p.box = box; p.b = (box - 1) / 2;
     p.beta_map = d->beta_map; p.policy = d->degenerate_policy;
     p.fast_weights = (d->flags & RPF_FLAG_FAST_WEIGHTS) ? 1 : 0;
-    {
-        const char *sm = std::getenv("RPF_STAGE_MASK"); // timing ablation knob for profiling; results are wrong when set
-        p.stage_mask = sm ? std::atoi(sm) : -1;
-    }
+    p.stage_mask = ctx->tun.stage_mask; // timing ablation knob (rpf_set_option); results are wrong unless -1
     const int64_t nmax64 = (int64_t)box * box * d->S;
     if (nmax64 > 49 * 64) return fail(ctx, RPF_E_UNSUPPORTED, "box*box*S > 3136: neighbourhood too large for the LDS-resident kernels");
     p.nmax = (int)nmax64;
@@ -152,7 +158,7 @@ int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const float *d_plan
     p.pmean = ctx->d_pmean; p.pstd = ctx->d_pstd; p.tfix = ctx->d_tfix; p.dfix = ctx->d_dfix;
     p.nbhd = ctx->d_nbhd; p.status = ctx->d_status;
     if (dbg_dev) p.dbg = *dbg_dev;
-    out.lds = lds_layout(p.S, p.nmax, p.bmax, table_in_lds(p.S, p.nmax, p.bmax)).total;
+    out.lds = lds_layout(p.S, p.nmax, p.bmax, table_in_lds(p.S, p.nmax, p.bmax, ctx->tun), ctx->tun).total;
     if ((int)out.lds > max_lds_per_block())
         return fail(ctx, RPF_E_UNSUPPORTED, "neighbourhood working set exceeds 160 KiB of LDS");
     return RPF_OK;
@@ -162,14 +168,14 @@ int32_t finish_counters(rpf_ctx *ctx, const rpf_desc *d, hipStream_t s);
 
 // One fused-filter pass over rows [p.row_begin, p.row_end).  When box*box*S is above what the one-wave kernels hold
 // (512 samples), the neighbourhood sizes are counted first and every kernel family filters its own pixel list with
-// LDS sized for its capacity (rpf_kernels.hip, "neighbourhood-size binning"); RPF_BINNING=0/1 overrides.
+// LDS sized for its capacity (rpf_kernels.hip, "neighbourhood-size binning"); option "binning" = 0/1 overrides.
 // Needs stage 1a's planes (pmean / pstd) for those rows.  Synchronises the stream when it bins (list sizes).
 int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p, hipStream_t s, int *launches) {
     bool bin = p.nmax > 512;
-    if (const char *e = std::getenv("RPF_BINNING")) bin = std::atoi(e) != 0;
+    if (ctx->tun.binning >= 0) bin = ctx->tun.binning != 0;
     if (p.dbg.nbhd_size || p.dbg.mi) { /* debug planes are written by whichever launch owns the pixel: fine */ }
     if (!bin) {
-        HIP_TRY(launch_filter_pass(p, s, nullptr));
+        HIP_TRY(launch_filter_pass(p, ctx->tun, s, nullptr));
         if (launches) ++*launches;
         return RPF_OK;
     }
@@ -203,7 +209,7 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p, hipStream_t s, i
         q.bmax = std::max(1, (int)std::sqrt((double)q.nmax));
         q.pix_list = ctx->d_lists + (size_t)c * HW;
         q.list_count = counts[c];
-        HIP_TRY(launch_filter_pass(q, s, nullptr));
+        HIP_TRY(launch_filter_pass(q, ctx->tun, s, nullptr));
         if (launches) ++*launches;
     }
     return RPF_OK;
@@ -293,6 +299,7 @@ int32_t finish_counters(rpf_ctx *ctx, const rpf_desc *d, hipStream_t s) {
     HIP_TRY(hipMemcpyAsync(nred, ctx->d_nred, sizeof(nred), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     c.samples_filtered = (int64_t)(d->row_end - d->row_begin) * d->W * d->S * d->n_box;
+    c.options_active = ctx->tun.is_default() ? 0 : 1;
     c.sum_nbhd = (int64_t)nred[0];
     c.max_nbhd = (int32_t)nred[1];
     c.nonfinite_pixels = hst[0];
@@ -483,7 +490,8 @@ int64_t rpf_lds_bytes_required(int32_t S, int32_t box) {
     const int nm = (int)nmax;
     int bmax = (int)std::sqrt((double)nm);
     if (bmax < 1) bmax = 1;
-    return lds_layout(S, nm, bmax, table_in_lds(S, nm, bmax)).total;
+    const Tuning tun;
+    return lds_layout(S, nm, bmax, table_in_lds(S, nm, bmax, tun), tun).total;
 }
 
 int32_t rpf_colour_from_planes_device(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, double *d_colour,
@@ -535,8 +543,28 @@ int32_t rpf_host_free(rpf_ctx *ctx, void *ptr) { // ctx may be NULL (a buffer ca
     return RPF_OK;
 }
 
+int32_t rpf_set_option(rpf_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx) return RPF_E_BADARG;
+    if (!name) return fail(ctx, RPF_E_BADARG, "option name is NULL");
+    const std::string n(name);
+    Tuning &t = ctx->tun;
+    if (n == "stage_mask") t.stage_mask = (int32_t)value;
+    else if (n == "binning" && value >= -1 && value <= 1) t.binning = (int32_t)value;
+    else if (n == "waves_per_pixel" && (value == 0 || value == 1 || value == 4)) t.waves_per_pixel = (int32_t)value;
+    else if (n == "table_in_lds" && value >= -1 && value <= 1) t.table_in_lds = (int32_t)value;
+    else if (n == "lds_pad" && value >= 0 && value <= 160 * 1024) t.lds_pad = (int32_t)value;
+    else return fail(ctx, RPF_E_BADARG, "unknown option or value out of range: " + n);
+    ctx->bin_valid = false;
+    return RPF_OK;
+}
+
 int32_t rpf_filter(rpf_ctx *ctx, const rpf_desc *d, const float *planes, const float *ray_weight,
                    float *sample_rgb_out, float *pixel_rgb_out) {
+    return rpf_filter_ex(ctx, d, planes, nullptr, ray_weight, sample_rgb_out, pixel_rgb_out, nullptr);
+}
+
+int32_t rpf_filter_ex(rpf_ctx *ctx, const rpf_desc *d, const float *planes, const double *colour64_in,
+                      const float *ray_weight, float *sample_rgb_out, float *pixel_rgb_out, double *colour64_out) {
     int32_t st = validate(ctx, d, true);
     if (st) return st;
     if (!planes) return fail(ctx, RPF_E_BADARG, "planes is NULL");
@@ -557,19 +585,24 @@ int32_t rpf_filter(rpf_ctx *ctx, const rpf_desc *d, const float *planes, const f
         if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
         return a.type == hipMemoryTypeHost;
     };
-    if (!(d->flags & (RPF_FLAG_TIMING | RPF_FLAG_NO_OVERLAP)) && pinned(planes) && pinned(ray_weight) &&
-        pinned(sample_rgb_out) && pinned(pixel_rgb_out))
+    if (!(d->flags & (RPF_FLAG_TIMING | RPF_FLAG_NO_OVERLAP)) && !colour64_in && !colour64_out && pinned(planes) &&
+        pinned(ray_weight) && pinned(sample_rgb_out) && pinned(pixel_rgb_out))
         return run_host_pipeline(ctx, d, planes, ray_weight, sample_rgb_out, pixel_rgb_out);
     // serial variant (per-kernel event timing needs it): upload, passes, download
     const double t0 = now_ms();
     HIP_TRY(hipMemcpyAsync(ctx->d_planes, planes, kNDim * ps * sizeof(float), hipMemcpyHostToDevice, s));
     if (ray_weight) HIP_TRY(hipMemcpyAsync(ctx->d_rayw, ray_weight, ps * sizeof(float), hipMemcpyHostToDevice, s));
-    HIP_TRY(launch_colour_from_planes(ctx->d_planes, ctx->d_colA, ps, s));
+    if (colour64_in) HIP_TRY(hipMemcpyAsync(ctx->d_colA, colour64_in, 3 * ps * sizeof(double), hipMemcpyHostToDevice, s));
+    else HIP_TRY(launch_colour_from_planes(ctx->d_planes, ctx->d_colA, ps, s));
     HIP_TRY(hipStreamSynchronize(s));
     const double t1 = now_ms();
     const int32_t fst = run_passes(ctx, d, ctx->d_planes, ctx->d_colA, s);
     if (fst != RPF_OK && fst != RPF_E_NONFINITE) return fst;
     const double t2 = now_ms();
+    if (colour64_out) {
+        HIP_TRY(hipMemcpyAsync(colour64_out, ctx->d_colA, 3 * ps * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     if (sample_rgb_out || pixel_rgb_out) {
         HIP_TRY(launch_reduce(ctx->d_colA, ray_weight ? ctx->d_rayw : nullptr, sample_rgb_out ? ctx->d_srgb : nullptr,
                               pixel_rgb_out ? ctx->d_prgb : nullptr, d->W, d->H, d->S, s));
@@ -673,6 +706,7 @@ int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *d, int32_t box, cons
     rpf_counters &c = ctx->counters;
     c = rpf_counters{};
     c.samples_filtered = (int64_t)(d->row_end - d->row_begin) * d->W * d->S;
+    c.options_active = ctx->tun.is_default() ? 0 : 1;
     c.sum_nbhd = (int64_t)nred[0];
     c.max_nbhd = (int32_t)nred[1];
     c.nonfinite_pixels = hst[0];

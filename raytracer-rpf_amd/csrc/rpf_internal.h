@@ -22,7 +22,7 @@ struct PassParams {
     int32_t box, b;        // b = (box-1)/2, rpf.cpp:561
     int32_t beta_map, policy;
     int32_t fast_weights;  // RPF_FLAG_FAST_WEIGHTS: fp32 pair arithmetic in stage 4
-    int32_t stage_mask;    // diagnostics only (env RPF_STAGE_MASK): bit0 stats chain, bit1 bins, bit2 MI, bit3 weights; -1 = all
+    int32_t stage_mask;    // diagnostics only (rpf_set_option "stage_mask"): bit0 stats chain, bit1 bins, bit2 MI, bit3 weights; -1 = all
     int32_t nmax;          // box*box*S: capacity of a neighbourhood
     int32_t bmax;          // floor(sqrt(nmax)): max histogram bins per axis
     double eps, seed, sigma_p;
@@ -43,19 +43,31 @@ struct PassParams {
     rpf_debug dbg;         // device pointers, any may be null
 };
 
+// Per-context tuning / diagnostic overrides (rpf_set_option).  Defaults = the library's own choices; nothing here is
+// read from the environment.  stage_mask != -1 skips stages (timing ablation: results are wrong) and is reported in
+// rpf_counters.options_active.
+struct Tuning {
+    int32_t waves_per_pixel = 0; // 0 auto, 1 or 4
+    int32_t table_in_lds = -1;   // -1 auto, 0 / 1
+    int32_t lds_pad = 0;         // extra LDS bytes per workgroup (occupancy experiments)
+    int32_t binning = -1;        // -1 auto (box*box*S > 512), 0 / 1
+    int32_t stage_mask = -1;     // bit0 stats chain, bit1 bins, bit2 MI, bit3 weights; -1 = all
+    bool is_default() const { return waves_per_pixel == 0 && table_in_lds == -1 && lds_pad == 0 && binning == -1 && stage_mask == -1; }
+};
+
 struct LdsLayout {
     uint32_t off_T, off_stat, off_hx, off_pair, off_mi, off_own, off_off, off_union, off_hist, total;
     uint32_t hist_stride; // bytes of one wave's histogram buffer
     uint32_t nw;          // waves per pixel (1 or 4)
 };
-LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds);
+LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun);
 int samples_per_lane(int nmax); // the K the filter kernel is instantiated with (0 = unsupported)
-bool table_in_lds(int S, int nmax, int bmax);
-int waves_per_pixel(int nmax);
+bool table_in_lds(int S, int nmax, int bmax, const Tuning &tun);
+int waves_per_pixel(int nmax, const Tuning &tun);
 
 hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s);
 hipError_t launch_pixel_stats_rows(const PassParams &p, int r0, int r1, hipStream_t s);
-hipError_t launch_filter_pass(const PassParams &p, hipStream_t s, uint32_t *lds_bytes_out);
+hipError_t launch_filter_pass(const PassParams &p, const Tuning &tun, hipStream_t s, uint32_t *lds_bytes_out);
 // neighbourhood-size binning (large box*box*S): count N per pixel, then deal the pixels into one list per kernel family
 constexpr int kNumClasses = 7;
 int class_capacity(int c);          // 64, 128, 256, 448, 832, 1600, 3136

@@ -26,8 +26,8 @@
 //   3c  alpha, beta, W_r_c lane-parallel through an LDS scratch area
 //   4   pair weights in z-space (A_i + B_j + u_i . z_j), fp64 (or fp32 with RPF_FLAG_FAST_WEIGHTS), LDS-free
 //       transposed-butterfly reductions (rpf_xlane.h)
-// Profiling knobs (environment, read on the host): RPF_STAGE_MASK (skip stages; results wrong), RPF_LDS_PAD
-// (lower occupancy), RPF_TABLE_IN_LDS, RPF_NW (waves per pixel), RPF_BINNING (size binning on/off).
+// Tuning / profiling knobs are per-context options (rpf_set_option -> struct Tuning): stage_mask (skip stages; results
+// wrong), lds_pad (lower occupancy), table_in_lds, waves_per_pixel, binning.  Nothing is read from the environment.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <cstdlib>
@@ -439,17 +439,59 @@ __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sS
     }
 }
 
-// One group of G (3 or 4) histograms, straight-line.  For marginals (JOINT = false) histogram u bins column
-// col0+u; for joints it bins (anchor, partner col(u)).  Slots kk < KD-1 are full by definition of KD (= ceil(n/64)),
-// so only the last slot carries the hole mask: `lastkey_ok` lanes exist, the others aim a +0 atomic at `hole`.
-// FULL = false (large neighbourhoods, KD = K): every slot carries its own mask (lane + 64*kk < n).
-template <int KD, int KW, int ZN, int G, bool JOINT, bool FULL, int PACK5>
-__device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, int lane, int n,
-                                         const int (&cols)[4], const uint32_t (&akey)[KD], bool last_ok, uint32_t hole,
-                                         int cells, uint64_t (&acc4)[4]) {
+// One group of G (3 or 4) joint histograms of one anchor column, straight-line: histogram u bins (anchor, partner
+// cols[u]).  Slots kk < KD-1 are full by definition of KD (= ceil(n/64)), so only the last slot carries the hole mask:
+// `last_ok` lanes exist, the others aim a +0 atomic at `hole`.  FULL = false (large neighbourhoods, KD = K): every
+// slot carries its own mask (lane + 64*kk < n).
+//
+// MARGINALS.  sum_i T[hx_i] of a column is needed once per column (19 of them).  Building 19 more histograms for that
+// is the most expensive way to get it: a marginal has only B cells, so the 64 lanes of an increment pile onto a handful
+// of addresses and same-address LDS atomics serialise (~1.8 cycles per lane, profiles/r01_lds_atomic_microbench.txt).
+// Instead the marginal counts are read off a joint histogram that is resident anyway, between its atomics and its
+// clearing store (one wave's LDS operations execute in order): hy_j = sum_i J[i][j] (column sums: the partner's
+// marginal) and hx_i = sum_j J[i][j] (row sums: the anchor's).  MARG bit 0: column sums of every histogram of the group
+// -> accm[u]; bit 1 (G == 3 only): row sums of histogram 0 -> accm[3].  Counts are integers: same totals, bit for bit.
+//   HALF (B <= 32): lane = (h, j), h = lane >> 5 takes every other row / column, the two halves meet in one
+//   v_permlane32_swap; NIT = compile-time trip count (>= ceil(B/2)), out-of-range steps re-read a valid cell and add 0.
+//   !HALF (B <= 64): lane = j, run-time loop over all B rows.
+template <bool HALF, int NIT, bool ROWS>
+__device__ __forceinline__ uint32_t marginal_counts(const uint32_t *sHist, int lane, int B) {
+    uint32_t tot = 0u;
+    if constexpr (HALF) {
+        const int j = lane & 31, h = lane >> 5;
+        const int jj = min(j, B - 1);
+        uint32_t v[NIT];
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int i = min(2 * t + h, B - 1);
+            v[t] = sHist[ROWS ? jj * B + i : i * B + jj];
+        }
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) tot += (2 * t + h < B) ? v[t] : 0u;
+        tot = xl::exch32<xl::OpSum>(tot, tot);          // both halves now hold the full count of bin j
+        tot = (j < B && h == 0) ? tot : 0u;            // one lane per bin contributes T[count] (T[0] == 0)
+    } else {
+        const int jj = min(lane, B - 1);
+#pragma unroll 4
+        for (int i = 0; i < B; ++i) tot += sHist[ROWS ? jj * B + i : i * B + jj];
+        tot = (lane < B) ? tot : 0u;
+    }
+    return tot;
+}
+
+template <int KD, int KW, int ZN, int G, bool FULL, int PACK5, int MARG>
+__device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, const uint64_t *ttab,
+                                         int lane, int n, int B, const int (&cols)[4], const uint32_t (&akey)[KD],
+                                         bool last_ok, uint32_t hole, int cells, uint64_t (&acc4)[4], uint64_t (&accm)[4]) {
+    static_assert(!(MARG & 2) || G == 3, "the anchor's row sums ride in the free fourth slot of a three-histogram group");
+    constexpr bool HALF = KD <= 13;                                   // K <= 13: N <= 832, B <= 28
+    constexpr int NIT = !FULL ? 14 : (ZN == 1 ? 8 : (ZN == 3 ? 9 : (ZN == 4 ? 10 : 11))); // B <= 16 / 17 / 19 / 22 (28 when !FULL)
     uint32_t old[2][KD];
+    uint32_t mcnt[2], rcnt = 0u;
     const uint32_t one = 1u, last_inc = last_ok ? 1u : 0u;
     auto slot_ok = [&](int kk) -> bool { return FULL ? (kk < KD - 1 ? true : last_ok) : (lane + kWave * kk < n); };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) accm[u] = 0ull;
 #pragma unroll
     for (int u = 0; u <= G; ++u) {
         if (u < G) {
@@ -457,8 +499,7 @@ __device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist,
             load_bins<KD, KW, PACK5>(sBinW, cols[u], lane, w);
 #pragma unroll
             for (int kk = 0; kk < KD; ++kk) {
-                uint32_t key = w.get(kk);
-                if (JOINT) key += akey[kk];                                  // mi.cpp:39
+                uint32_t key = w.get(kk) + akey[kk];                         // mi.cpp:39
                 if (FULL) {
                     if (kk == KD - 1) key = last_ok ? key : hole;
                     old[u & 1][kk] = atomicAdd(&sHist[key], kk == KD - 1 ? last_inc : one);
@@ -467,7 +508,13 @@ __device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist,
                     old[u & 1][kk] = atomicAdd(&sHist[ok ? key : hole], ok ? 1u : 0u);
                 }
             }
-            zero_cells<(JOINT ? ZN : (ZN > 0 ? 1 : 0))>(sHist, cells, lane);
+            if constexpr (MARG != 0) {
+                wsync(); // the counts other lanes' atomics left are read below (in-order LDS: no wait, only program order)
+                if constexpr (MARG & 1) mcnt[u & 1] = marginal_counts<HALF, NIT, false>(sHist, lane, B);
+                if constexpr ((MARG & 2) != 0) if (u == 0) rcnt = marginal_counts<HALF, NIT, true>(sHist, lane, B);
+                wsync();
+            }
+            zero_cells<ZN>(sHist, cells, lane);
         }
         if (u >= 1) {
             uint64_t d[KD];
@@ -477,8 +524,10 @@ __device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist,
 #pragma unroll
             for (int kk = 0; kk < KD - 1; ++kk) a += slot_ok(kk) ? d[kk] : 0ull;
             acc4[u - 1] = a;
+            if constexpr (MARG & 1) accm[u - 1] = ttab[mcnt[(u - 1) & 1]];
         }
     }
+    if constexpr ((MARG & 2) != 0) accm[3] = ttab[rcnt];
 #pragma unroll
     for (int u = G; u < 4; ++u) acc4[u] = 0ull;
 }
@@ -640,40 +689,22 @@ __device__ __forceinline__ void mi_stage_tiny(const uint32_t *sBinW, uint32_t *s
     }
 }
 
-// NW > 1: the 30 histogram groups (5 marginal + 25 joint) are dealt round-robin to the NW waves of the pixel; every
-// wave has its own histogram buffer and covers all n samples of its groups, so the stage needs no barrier.
+// NW > 1: the 25 histogram groups are dealt round-robin to the NW waves of the pixel; every wave has its own histogram
+// buffer and covers all n samples of its groups, so the stage needs no barrier.
+// Marginal sums (sHXf) come out of the joint histograms (mi_group, "MARGINALS"): the partners' from the groups of the
+// first anchor (r0: f0..f11 and c0..c2 are all partners there), the anchors' r0, r1, p0, p1 from the row sums of the
+// first histogram of their c-partner group.
 template <int KD, int KW, int ZN, bool FULL, int PACK5, int NW = 1>
-__device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, uint64_t *sHXf,
-                                         uint64_t *sPairF, int lane, int n, int B, int wv = 0) {
+__device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, const uint64_t *ttab,
+                                         uint64_t *sHXf, uint64_t *sPairF, int lane, int n, int B, int wv = 0) {
     int gi = 0; // running group number (wave-uniform)
     auto mine = [&]() { const bool m = (NW == 1) || (gi % NW) == wv; ++gi; return m; };
     const int ncell2 = B * B;
     const bool last_ok = (lane + kWave * (KD - 1)) < n;     // does this lane's last sample slot exist?
-    const uint32_t hole1 = (uint32_t)min(lane, B - 1);      // harmless, spread-out targets of the +0 atomics
-    const uint32_t hole2 = (uint32_t)min(lane, ncell2 - 1);
+    const uint32_t hole2 = (uint32_t)min(lane, ncell2 - 1); // harmless, spread-out targets of the +0 atomics
     zero_cells<ZN>(sHist, ncell2, lane);
     uint32_t akey[KD];
-#pragma unroll
-    for (int kk = 0; kk < KD; ++kk) akey[kk] = 0u;
-
-    // ---- marginals: sum_i T[hx_i] per column; 19 columns = 4 groups of 4 + one group of 3
-#pragma unroll 1
-    for (int c0 = 0; c0 < 16; c0 += 4) {
-        if (!mine()) continue;
-        uint64_t acc4[4];
-        const int cols[4] = {c0, c0 + 1, c0 + 2, c0 + 3};
-        mi_group<KD, KW, ZN, 4, false, FULL, PACK5>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole1, B, acc4);
-        const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
-        if ((lane & 15) == 0) sHXf[c0 + xl::slot4(lane)] = tot;
-    }
-    if (mine()) {
-        uint64_t acc4[4];
-        const int cols[4] = {16, 17, 18, 18};
-        mi_group<KD, KW, ZN, 3, false, FULL, PACK5>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole1, B, acc4);
-        const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
-        if ((lane & 15) == 0 && xl::slot4(lane) < 3) sHXf[16 + xl::slot4(lane)] = tot;
-    }
-    // ---- joint histograms, grouped by an anchor column whose (bin * B) stays in registers
+    // joint histograms, grouped by an anchor column whose (bin * B) stays in registers
     //   anchors 0..3 = r0, r1, p0, p1 with partners f0..f11, c0..c2 ; anchors 4..6 = c0..c2 with f0..f11
 #pragma unroll 1
     for (int g = 0; g < 7; ++g) {
@@ -690,16 +721,29 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
 #pragma unroll 1
         for (int i0 = 0; i0 < 12; i0 += 4) { // partners f0..f11
             if (!mine()) continue;
-            uint64_t acc4[4];
+            uint64_t acc4[4], accm[4];
             const int cols[4] = {kColF + i0, kColF + i0 + 1, kColF + i0 + 2, kColF + i0 + 3};
-            mi_group<KD, KW, ZN, 4, true, FULL, PACK5>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole2, ncell2, acc4);
+            if (g == 0) { // wave-uniform: the first anchor's groups also deliver their partners' marginals
+                mi_group<KD, KW, ZN, 4, FULL, PACK5, 1>(sBinW, sHist, dtab, ttab, lane, n, B, cols, akey, last_ok, hole2, ncell2, acc4, accm);
+                const uint64_t mt = xl::reduce4<xl::OpSum>(accm);
+                if ((lane & 15) == 0) sHXf[kColF + i0 + xl::slot4(lane)] = mt;
+            } else {
+                mi_group<KD, KW, ZN, 4, FULL, PACK5, 0>(sBinW, sHist, dtab, ttab, lane, n, B, cols, akey, last_ok, hole2, ncell2, acc4, accm);
+            }
             const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
             if ((lane & 15) == 0) sPairF[pair_index(i0 + xl::slot4(lane))] = tot;
         }
-        if (g < 4 && mine()) { // partners c0..c2 (wave-uniform branch)
-            uint64_t acc4[4];
+        if (g < 4 && mine()) { // partners c0..c2 (wave-uniform branch); slot 3 carries the anchor's own marginal
+            uint64_t acc4[4], accm[4];
             const int cols[4] = {kColC, kColC + 1, kColC + 2, kColC + 2};
-            mi_group<KD, KW, ZN, 3, true, FULL, PACK5>(sBinW, sHist, dtab, lane, n, cols, akey, last_ok, hole2, ncell2, acc4);
+            if (g == 0) mi_group<KD, KW, ZN, 3, FULL, PACK5, 3>(sBinW, sHist, dtab, ttab, lane, n, B, cols, akey, last_ok, hole2, ncell2, acc4, accm);
+            else mi_group<KD, KW, ZN, 3, FULL, PACK5, 2>(sBinW, sHist, dtab, ttab, lane, n, B, cols, akey, last_ok, hole2, ncell2, acc4, accm);
+            const uint64_t mt = xl::reduce4<xl::OpSum>(accm);
+            if ((lane & 15) == 0) {
+                const int sl = xl::slot4(lane);
+                if (sl == 3) sHXf[acol] = mt;
+                else if (g == 0) sHXf[kColC + sl] = mt;
+            }
             const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
             if ((lane & 15) == 0 && xl::slot4(lane) < 3) sPairF[pair_index(12 + xl::slot4(lane))] = tot;
         }
@@ -1285,10 +1329,10 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
     if constexpr (K >= KD_) {                                                                                \
         if constexpr (KD_ == 1) mi_stage_tiny<KW, PACK5>(sBinW, sHist, p.tfix, sHXf, sPairF, lane, n, B); /* B*B <= 64 */ \
         else if constexpr (KD_ == 2) mi_stage_deep<KD_, KW, 1, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); /* B*B <= 121 */ \
-        else if (B * B <= 256) mi_stage<KD_, KW, 1, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); \
-        else if (B * B <= 320) mi_stage<KD_, KW, 3, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); \
-        else if (B * B <= 384) mi_stage<KD_, KW, 4, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); \
-        else mi_stage<KD_, KW, 2, true, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B);               \
+        else if (B * B <= 256) mi_stage<KD_, KW, 1, true, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B); \
+        else if (B * B <= 320) mi_stage<KD_, KW, 3, true, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B); \
+        else if (B * B <= 384) mi_stage<KD_, KW, 4, true, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B); \
+        else mi_stage<KD_, KW, 2, true, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B);               \
     }
             switch (kdyn) {
             case 1: RPF_MI_CASE(1) break;
@@ -1302,7 +1346,7 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
             }
 #undef RPF_MI_CASE
         } else {
-            mi_stage<K, KW, 0, false, PACK5, NW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B, wv);
+            mi_stage<K, KW, 0, false, PACK5, NW>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B, wv);
         }
     }
     bsync();
@@ -1476,7 +1520,12 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
                 for (int k = 0; k < 3; ++k) cj[k] = pc[k];
                 if constexpr (NW > 1) fetch17(j + kWave); // the next slot's gathers fly while this one is weighted
                 // straight-line over the kOwnBlock own samples (a missing one re-reads the last row and its weight is
-                // forced to 0) so their dependent chains interleave; the 17-term dot product runs as four partial sums
+                // forced to 0) so their dependent chains interleave; the 17-term dot product runs as four partial sums.
+                // exp(-E) is +0 for E > 745.14 (below the smallest subnormal), and with sigma^2 = 0.002^2 / (1-W)^2 that
+                // is what nearly every cross pair gets: when every lane's exponent is beyond 746 the exp()
+                // evaluation is skipped (wave-uniform branch) -- the weights are the same +0 (a NaN exponent fails the
+                // comparison and takes the exp path, which propagates it); the accumulations still run, so a
+                // non-finite colour times 0 gives the reference's NaN.
 #pragma unroll
                 for (int ii = 0; ii < kOwnBlock; ++ii) {
                     const int i = i0 + ii;
@@ -1495,7 +1544,8 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
                     }
                     e0 = fma(ui[16], zj[16], e0);
                     const double E = (e0 + e1) + (e2 + e3);
-                    double w = exp(-E);                         // rpf.cpp:667-670
+                    double w = 0.0;
+                    if (!__all(E > 746.0)) w = exp(-E);         // rpf.cpp:667-670
                     w = live ? w : 0.0;
                     sw[ii] += w;                                // rpf.cpp:691
                     s0[ii] = fma(w, cj[0], s0[ii]);             // rpf.cpp:692 (raw neighbourhood colours)
@@ -1836,30 +1886,28 @@ int samples_per_lane(int nmax) {
 }
 
 // waves per pixel: 4 once a neighbourhood is too large for more than a few one-wave workgroups to share a CU's
-// LDS (K >= 25: 32 spp and up at box 7); RPF_NW=1 / RPF_NW=4 override for experiments (4 needs K >= 13)
-int waves_per_pixel(int nmax) {
+// LDS (K >= 25: 32 spp and up at box 7); option "waves_per_pixel" = 1 / 4 overrides for experiments (4 needs K >= 13)
+int waves_per_pixel(int nmax, const Tuning &tun) {
     const int K = samples_per_lane(nmax);
     int nw = K >= 25 ? 4 : 1;
-    if (const char *e = std::getenv("RPF_NW")) {
-        const int v = std::atoi(e);
-        if (v == 1 || (v == 4 && K >= 13)) nw = v;
-    }
+    const int v = tun.waves_per_pixel;
+    if (v == 1 || (v == 4 && K >= 13)) nw = v;
     return nw;
 }
 
-bool table_in_lds(int S, int nmax, int bmax) {
+bool table_in_lds(int S, int nmax, int bmax, const Tuning &tun) {
     // One-wave kernels read the D table through L1: 3 .. 25 KiB of LDS per workgroup buy resident waves, which is what
     // those latency-bound kernels need.  The four-wave kernels run 1-2 workgroups per CU, every table look-up is a
     // round trip none of their few waves can cover, and one copy serves four waves: they keep the table in LDS
-    // whenever that costs no resident workgroup (32 spp: 161 -> 206 ms without it).  RPF_TABLE_IN_LDS=0/1 overrides.
+    // whenever that costs no resident workgroup (32 spp: 161 -> 206 ms without it).  Option "table_in_lds" overrides.
     if ((uint32_t)nmax * 8u > 65536u) return false;
-    if (const char *e = std::getenv("RPF_TABLE_IN_LDS")) return std::atoi(e) != 0;
-    if (waves_per_pixel(nmax) == 1) return false;
-    const uint32_t without = lds_layout(S, nmax, bmax, false).total, with = lds_layout(S, nmax, bmax, true).total;
+    if (tun.table_in_lds >= 0) return tun.table_in_lds != 0;
+    if (waves_per_pixel(nmax, tun) == 1) return false;
+    const uint32_t without = lds_layout(S, nmax, bmax, false, tun).total, with = lds_layout(S, nmax, bmax, true, tun).total;
     return with <= (uint32_t)max_lds_per_block() && (uint32_t)max_lds_per_block() / with == (uint32_t)max_lds_per_block() / without;
 }
 
-LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
+LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun) {
     LdsLayout L{};
     const int K = samples_per_lane(nmax);
     const uint32_t KW = (uint32_t)pack_words(K);
@@ -1873,7 +1921,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     L.off_own = o; o += align_up((uint32_t)S * kNDim * 8u, 16);
     L.off_off = o; o += align_up((uint32_t)nmax * 4u, 16);
     L.off_union = o;
-    const int nw = waves_per_pixel(nmax);
+    const int nw = waves_per_pixel(nmax, tun);
     L.nw = (uint32_t)nw;
     const uint32_t stage = nw > 1 ? align_up((uint32_t)(nw - 2) * kNDim * (kStageChunk + 1) * 8u, 16) // one chunk per producer wave
                                   : align_up(kNDim * (kStageHalf + 1) * 8, 16);
@@ -1889,7 +1937,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds) {
     if (cells < 256u) cells = 256u;           // the buffer doubles as scratch (stage 1b masks, stage 3c, flags)
     L.hist_stride = align_up(cells * 4u, 16);
     o += L.hist_stride * (uint32_t)nw;        // one histogram buffer per wave of the pixel
-    if (const char *e = std::getenv("RPF_LDS_PAD")) o += (uint32_t)std::atoi(e); // occupancy experiment knob
+    if (tun.lds_pad > 0) o += (uint32_t)tun.lds_pad; // occupancy experiment knob
     L.total = o;
     return L;
 }
@@ -1909,9 +1957,9 @@ hipError_t launch_pixel_stats_rows(const PassParams &p, int r0, int r1, hipStrea
 
 hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s) { return launch_pixel_stats_rows(p, 0, p.H, s); }
 
-hipError_t launch_filter_pass(const PassParams &p, hipStream_t s, uint32_t *lds_bytes_out) {
-    const bool t_in_lds = table_in_lds(p.S, p.nmax, p.bmax);
-    const LdsLayout L = lds_layout(p.S, p.nmax, p.bmax, t_in_lds);
+hipError_t launch_filter_pass(const PassParams &p, const Tuning &tun, hipStream_t s, uint32_t *lds_bytes_out) {
+    const bool t_in_lds = table_in_lds(p.S, p.nmax, p.bmax, tun);
+    const LdsLayout L = lds_layout(p.S, p.nmax, p.bmax, t_in_lds, tun);
     if (lds_bytes_out) *lds_bytes_out = L.total;
     if ((int)L.total > max_lds_per_block()) return hipErrorInvalidValue;
     const int rows_own = p.row_end - p.row_begin;

@@ -41,6 +41,11 @@ template <> struct Words<float> {
     __device__ __forceinline__ static void split(float v, uint32_t (&w)[1]) { w[0] = __float_as_uint(v); }
     __device__ __forceinline__ static float join(const uint32_t (&w)[1]) { return __uint_as_float(w[0]); }
 };
+template <> struct Words<uint32_t> {
+    static constexpr int N = 1;
+    __device__ __forceinline__ static void split(uint32_t v, uint32_t (&w)[1]) { w[0] = v; }
+    __device__ __forceinline__ static uint32_t join(const uint32_t (&w)[1]) { return w[0]; }
+};
 template <> struct Words<double> {
     static constexpr int N = 2;
     __device__ __forceinline__ static void split(double v, uint32_t (&w)[2]) {

@@ -25,7 +25,7 @@ FLAG_NO_OVERLAP = 4
 EXPORTS = ["rpf_version", "rpf_status_string", "rpf_create", "rpf_destroy", "rpf_last_error", "rpf_filter",
            "rpf_filter_device", "rpf_colour_from_planes_device", "rpf_reduce_device", "rpf_stage_pixel_stats",
            "rpf_filter_pass_debug", "rpf_query_counters", "rpf_lds_bytes_required", "rpf_selftest_udiv", "rpf_feature_images",
-           "rpf_host_alloc", "rpf_host_free"]
+           "rpf_host_alloc", "rpf_host_free", "rpf_filter_ex", "rpf_set_option"]
 
 
 class Desc(C.Structure):
@@ -45,7 +45,7 @@ class Counters(C.Structure):
     _fields_ = [("samples_filtered", C.c_int64), ("sum_nbhd", C.c_int64), ("nonfinite_pixels", C.c_int64),
                 ("max_nbhd", C.c_int32), ("first_bad_pixel", C.c_int32), ("filter_kernel_ms", C.c_float),
                 ("stats_kernel_ms", C.c_float), ("device_total_ms", C.c_float), ("h2d_ms", C.c_float),
-                ("d2h_ms", C.c_float), ("filter_kernel_launches", C.c_int32)]
+                ("d2h_ms", C.c_float), ("filter_kernel_launches", C.c_int32), ("options_active", C.c_int32)]
 
 
 class RpfError(RuntimeError):
@@ -81,6 +81,8 @@ def load():
         L.rpf_last_error.restype = C.c_char_p
         L.rpf_last_error.argtypes = [C.c_void_p]
         L.rpf_filter.argtypes = [C.c_void_p, C.POINTER(Desc)] + [C.c_void_p] * 4
+        L.rpf_filter_ex.argtypes = [C.c_void_p, C.POINTER(Desc)] + [C.c_void_p] * 6
+        L.rpf_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.rpf_filter_device.argtypes = [C.c_void_p, C.POINTER(Desc)] + [C.c_void_p] * 3
         L.rpf_colour_from_planes_device.argtypes = [C.c_void_p, C.POINTER(Desc)] + [C.c_void_p] * 3
         L.rpf_reduce_device.argtypes = [C.c_void_p, C.POINTER(Desc)] + [C.c_void_p] * 5
@@ -152,6 +154,10 @@ class Context:
             raise RpfError(st, self._L.rpf_last_error(self._h).decode())
         return st
 
+    def set_option(self, name, value):
+        """per-context tuning / diagnostic override (rpf_set_option); see include/rpf_hip.h for the names"""
+        self._check(self._L.rpf_set_option(self._h, name.encode(), int(value)))
+
     def counters(self):
         c = Counters()
         self._check(self._L.rpf_query_counters(self._h, C.byref(c)))
@@ -169,13 +175,19 @@ class Context:
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def filter(self, planes, desc, ray_weight=None, want_samples=True, want_pixels=True, allow_nonfinite=False,
-               out_samples=None, out_pixels=None):
+               out_samples=None, out_pixels=None, colour64_in=None, want_colour64=False):
         planes = np.ascontiguousarray(planes, np.float32)
         assert planes.shape == (NDIM, desc.H, desc.W, desc.S), planes.shape
         rw = None if ray_weight is None else np.ascontiguousarray(ray_weight, np.float32)
         srgb = out_samples if out_samples is not None else (
             np.empty((3, desc.H, desc.W, desc.S), np.float32) if want_samples else None)
         prgb = out_pixels if out_pixels is not None else (np.empty((desc.H, desc.W, 3), np.float32) if want_pixels else None)
+        if colour64_in is not None or want_colour64:
+            cin = None if colour64_in is None else np.ascontiguousarray(colour64_in, np.float64)
+            c64 = np.empty((3, desc.H, desc.W, desc.S)) if want_colour64 else None
+            st = self._L.rpf_filter_ex(self._h, C.byref(desc), _p(planes), _p(cin), _p(rw), _p(srgb), _p(prgb), _p(c64))
+            self._check(st, allow=(E_NONFINITE,) if allow_nonfinite else ())
+            return srgb, prgb, st, c64
         st = self._L.rpf_filter(self._h, C.byref(desc), _p(planes), _p(rw), _p(srgb), _p(prgb))
         self._check(st, allow=(E_NONFINITE,) if allow_nonfinite else ())
         return srgb, prgb, st

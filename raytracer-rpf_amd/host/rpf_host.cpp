@@ -101,7 +101,7 @@ int RPFFilter::run(SamplingFilm &film, const std::vector<int> &boxes, std::vecto
 
     // marshal AoS doubles [x][y][s][19] -> SoA fp32 planes [19][y][x][s] (values are fp32-valued: pbrt Float)
     const size_t ps = (size_t)W * H * S;
-    if (!planes_.resize(ctx_, RPF_NDIM * ps) || !rayw_.resize(ctx_, ps) || !srgb_.resize(ctx_, 3 * ps)) {
+    if (!planes_.resize(ctx_, RPF_NDIM * ps) || !rayw_.resize(ctx_, ps) || !col64_.resize(ctx_, 3 * ps)) {
         err_ = "page-locked staging allocation failed";
         return RPF_E_NOMEM;
     }
@@ -112,6 +112,9 @@ int RPFFilter::run(SamplingFilm &film, const std::vector<int> &boxes, std::vecto
             const size_t base = ((size_t)y * W + x) * S;
             for (size_t s = 0; s < S; ++s) {
                 for (int d = 0; d < RPF_NDIM; ++d) planes_[(size_t)d * ps + base + s] = (float)px[s].data[d];
+                // colours cross the boundary as the doubles the film holds (sd.h:205): after a previous
+                // ApplyRPFFilter call they are no longer fp32-valued, and rounding them would move histogram bins
+                for (int c = 0; c < 3; ++c) col64_[(size_t)c * ps + base + s] = px[s].getColorI(c);
                 rayw_[base + s] = px[s].rayWeight;
             }
         }
@@ -125,7 +128,8 @@ int RPFFilter::run(SamplingFilm &film, const std::vector<int> &boxes, std::vecto
     d.beta_map = beta_map; d.degenerate_policy = degenerate_policy;
     d.eps = eps; d.sigma_seed = sigma_seed;
     if (pixel_rgb) pixel_rgb->resize((size_t)W * H * 3);
-    const int32_t st = rpf_filter(ctx_, &d, planes_.data(), rayw_.data(), srgb_.data(), pixel_rgb ? pixel_rgb->data() : nullptr);
+    const int32_t st = rpf_filter_ex(ctx_, &d, planes_.data(), col64_.data(), rayw_.data(), nullptr,
+                                     pixel_rgb ? pixel_rgb->data() : nullptr, col64_.data());
     rpf_query_counters(ctx_, &counters_);
     if (st != RPF_OK) err_ = std::string(rpf_status_string(st)) + ": " + rpf_last_error(ctx_);
     if (st != RPF_OK && st != RPF_E_NONFINITE) return st;
@@ -137,7 +141,7 @@ int RPFFilter::run(SamplingFilm &film, const std::vector<int> &boxes, std::vecto
             SampleDataSet &px = film.samples[x][y];
             const size_t base = ((size_t)y * W + x) * S;
             for (size_t s = 0; s < S; ++s)
-                for (int c = 0; c < 3; ++c) px[s].setColorI(c, (double)srgb_[(size_t)c * ps + base + s]);
+                for (int c = 0; c < 3; ++c) px[s].setColorI(c, col64_[(size_t)c * ps + base + s]);
         }
     return st;
 }
@@ -161,11 +165,14 @@ extern "C" int32_t rpf_host_apply_filter_aos(double *aos, const float *ray_weigh
             }
         }
     RPFFilter f(device);
-    f.beta_map = beta_map;
+    f.beta_map = beta_map & 0xff;
     f.degenerate_policy = policy;
     std::vector<float> pix;
-    int st;
-    if (n_box == 1 && !pixel_rgb_out) st = f.ApplyRPFFilter(film, 16, box_sizes[0]);
+    int st = RPF_OK;
+    if (beta_map & RPF_HOST_PER_BOX_CALLS) {
+        // the reference's own call shape (rpf.cpp:767-775): one ApplyRPFFilter per box size on the same film
+        for (int i = 0; i < n_box && (st == RPF_OK); ++i) st = f.ApplyRPFFilter(film, 16, box_sizes[i]);
+    } else if (n_box == 1 && !pixel_rgb_out) st = f.ApplyRPFFilter(film, 16, box_sizes[0]);
     else st = f.FilterAndReduce(film, std::vector<int>(box_sizes, box_sizes + n_box), pixel_rgb_out ? &pix : nullptr);
     if (err && err_len > 0) std::snprintf(err, err_len, "%s", f.last_error().c_str());
     if (st != RPF_OK && st != RPF_E_NONFINITE) return st;
@@ -175,7 +182,7 @@ extern "C" int32_t rpf_host_apply_filter_aos(double *aos, const float *ray_weigh
                 const size_t o = (((size_t)x * H + y) * S + s);
                 std::memcpy(aos + o * RPF_NDIM, film.samples[x][y][s].data, sizeof(double) * RPF_NDIM);
             }
-    if (pixel_rgb_out) std::memcpy(pixel_rgb_out, pix.data(), pix.size() * sizeof(float));
+    if (pixel_rgb_out && !pix.empty()) std::memcpy(pixel_rgb_out, pix.data(), pix.size() * sizeof(float));
     return st;
 }
 

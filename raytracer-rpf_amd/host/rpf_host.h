@@ -131,14 +131,19 @@ class RPFFilter {
     rpf_ctx *ctx_ = nullptr;
     std::string err_;
     rpf_counters counters_{};
-    PinnedArray<float> planes_, rayw_, srgb_; // staging for the AoS film
+    PinnedArray<float> planes_, rayw_; // staging for the AoS film
+    PinnedArray<double> col64_;        // ... and its colours, carried as doubles in both directions (rpf_filter_ex)
 };
 
 } // namespace rpf_host
 
+// OR-ed into the beta_map argument of rpf_host_apply_filter_aos: run the box list as the reference's Render loop does,
+// one RPFFilter::ApplyRPFFilter(film, 16, box) call per box size on the same film (rpf.cpp:767-775)
+#define RPF_HOST_PER_BOX_CALLS 0x100
+
 extern "C" {
 // test / FFI doorway: aos is double [W][H][S][19] in SamplingFilm order, ray_weight float [W][H][S] (may be NULL);
-// colours are filtered in place.  Returns an rpf_status.
+// colours are filtered in place (as doubles).  Returns an rpf_status.
 int32_t rpf_host_apply_filter_aos(double *aos, const float *ray_weight, int32_t W, int32_t H, int32_t S,
                                   const int32_t *box_sizes, int32_t n_box, int32_t beta_map, int32_t policy,
                                   int32_t device, float *pixel_rgb_out, char *err, int32_t err_len);

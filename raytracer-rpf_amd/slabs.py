@@ -18,7 +18,12 @@ def partition_rows(H, world, rank):
 
 
 def slab_for(H, world, rank, halo):
+    """rank's slab; every rank must own at least `halo` rows, because a neighbour's halo is filled from this rank's
+    OWNED boundary rows only (a thinner slab would have to forward rows it does not own)"""
     a, b = partition_rows(H, world, rank)
+    if world > 1 and b - a < halo:
+        raise ValueError("row slab of rank %d has %d rows, fewer than the %d halo rows its neighbours need: "
+                         "use fewer ranks (H = %d, world = %d)" % (rank, b - a, halo, H, world))
     return Slab(a, b, min(halo, a), min(halo, H - b))
 
 
@@ -36,6 +41,7 @@ def exchange_halo(t, slab, rank, world, group=None):
         return
     n_own = slab.row1 - slab.row0
     top0 = slab.halo_top  # first owned buffer row
+    assert n_own >= max(slab.halo_top, slab.halo_bottom), "slab thinner than its halo (see slab_for)"
     ops, recvs = [], []
     # gloo moves host memory only: device tensors are staged through the host (CPU tests, single-GPU rehearsals of the
     # multi-rank path); nccl (= RCCL) sends device memory directly over xGMI

@@ -1,8 +1,8 @@
-# VALU / LDS / SALU / VMEM instruction counts of the fused kernel per stage, from differences between RPF_STAGE_MASK runs
+# VALU / LDS / SALU / VMEM instruction counts of the fused kernel per stage, from differences between stage_mask runs
 export TMPDIR=/tmp
 for m in -1 0 1 3 7; do
   rm -rf gpurun_out/ibs_$m
-  RPF_STAGE_MASK=$m rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES --output-format csv -d gpurun_out/ibs_$m -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES --output-format csv -d gpurun_out/ibs_$m -- python3 bench.py --option stage_mask=$m --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
 python3 - <<'PY'
 import csv, glob

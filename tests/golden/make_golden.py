@@ -14,6 +14,9 @@
                  cannot be compiled here: glog/OpenEXR absent) and is "parity unpinned" -- these files pin
                  GPU <-> oracle and guard the oracle against regressions.
 
+  clustered_10x8x8.rpfb (+ _expected.npz)   an on-disk feature buffer in the .rpfb wire format and the oracle's
+                 two-pass result on it.
+
 Fixtures are data only: inputs and expected outputs.
 """
 import os
@@ -43,7 +46,30 @@ def mi_cases(rng):
     return cases
 
 
+def rpfb_fixture():
+    """clustered_10x8x8.rpfb: an on-disk feature buffer (feature_buffer.save_rpfb, with a ray-weight plane) and the
+    oracle's two-pass {7, 5} result on it (filtered colours + pixel means): closes the loop file -> HIP path."""
+    W, H, S = 10, 8, 8
+    planes = fb.synth_planes(W, H, S, seed=77, sigma_f=1e-3, sigma_c=0.01, mode="clustered")
+    rw = (0.5 + np.random.default_rng(77).random((H, W, S))).astype(np.float32)
+    fb.save_rpfb(os.path.join(HERE, "clustered_10x8x8.rpfb"), planes, rw)
+    c = None
+    for box in (7, 5):
+        c = O.filter_pass(planes, O.make_desc(W, H, S, box=box, policy=O.DEGEN_EPS, n_threads=1), colour_in=c,
+                          debug=False)["colour"]
+    pix = O.pixel_mean(c, O.make_desc(W, H, S), rw)
+    np.savez_compressed(os.path.join(HERE, "clustered_10x8x8_expected.npz"), colour=c, pixel_rgb=pix,
+                        boxes=np.array([7, 5], np.int32), policy=O.DEGEN_EPS,
+                        source="oracle/rpf_oracle.c, EPS policy, beta map REF_GCC11_O3, on clustered_10x8x8.rpfb")
+    cin = planes[2:5].astype(np.float64)
+    print("clustered_10x8x8.rpfb  %.1f KB, activity %.3e" % (
+        os.path.getsize(os.path.join(HERE, "clustered_10x8x8.rpfb")) / 1024, np.linalg.norm(c - cin) / np.linalg.norm(cin)))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "rpfb":
+        O.build(force=False)
+        return rpfb_fixture()
     O.build(force=False)
     if not O.ref_available():
         sys.exit("oracle/_ref/libref_mi.so missing: this script must run where /root/reference exists")
@@ -104,6 +130,7 @@ def main():
                             nonfinite_pixels=r["nonfinite_pixels"], activity=act,
                             source="oracle/rpf_oracle.c (beta map REF_GCC11_O3); inputs stored verbatim")
         print("%-36s mean N %.1f activity %.3e status %d" % (name, r["sum_nbhd"] / (gen["W"] * gen["H"]), act, r["status"]))
+    rpfb_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%-40s %7.1f KB" % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))

@@ -52,6 +52,138 @@ def test_stage1a_pixel_stats_bit_exact(ctx, hipmod, oracle):
     assert np.array_equal(s, so, equal_nan=True)
 
 
+def test_config1_shape_small_neighbourhoods_400x400x8(ctx, hipmod, oracle):
+    """BASELINE configs[0] stand-in (400x400, 8 spp, EPS policy): a captured killeroo buffer keeps N = S for ~94 % of its
+    pixels and the reference itself aborts on it (F2); pbrt cannot be built here, so the stand-in is the
+    seeded generator with an in-pixel jitter small enough that the 3-sigma test rejects nearly every neighbour.  Every
+    stage output of the full frame against the oracle."""
+    W, H, S = 400, 400, 8
+    for sf, lo, hi in ((1e-5, 8.0, 30.0), (3e-3, 20.0, 200.0)):
+        planes = fb.synth_planes(W, H, S, seed=1, sigma_f=sf, sigma_c=0.01, mode="smooth")
+        got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS), box=7)
+        want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7, policy=oracle.DEGEN_EPS))
+        check_pass(got, want)
+        assert got["nonfinite_pixels"] == want["nonfinite_pixels"] == 0
+        mean_n = want["sum_nbhd"] / (W * H)
+        assert lo <= mean_n <= hi, mean_n
+
+
+def test_config3_shape_four_passes_1080p16(ctx, hipmod, oracle):
+    """BASELINE configs[2] stand-in: 1920x1080x16 spp, four passes {7,7,5,5}, EPS policy (the reference enables {7}
+    only, rpf.cpp:767; the list is this build's).  After EVERY pass: bitwise determinism, every colour inside the
+    convex hull of its window's input colours, and the oracle on three full-width rows fed with the colours the
+    previous pass left (carried as doubles, rpf.cpp:732)."""
+    import torch
+    W, H, S = 1920, 1080, 16
+    dev = torch.device("cuda", 0)
+    planes = fb.synth_planes(W, H, S, xp=fb.torch_backend(dev), mode="clustered", sigma_f=1e-3, sigma_c=0.01).contiguous()
+    col = planes[2:5].to(torch.float64).contiguous()
+    stream = torch.cuda.current_stream().cuda_stream
+    pad = torch.nn.functional.pad
+    r0, R = 531, 3
+    moved = 0.0
+    for box in (7, 7, 5, 5):
+        b = (box - 1) // 2
+        desc = hipmod.make_desc(W, H, S, boxes=(box,), policy=hipmod.DEGEN_EPS)
+        outs = []
+        for _ in range(2):
+            c = col.clone()
+            ctx.filter_device(desc, planes.data_ptr(), c.data_ptr(), stream)
+            outs.append(c)
+        torch.cuda.synchronize()
+        out = outs[0]
+        assert torch.equal(out, outs[1])
+        cnt = ctx.counters()
+        assert cnt.nonfinite_pixels == 0 and S <= cnt.max_nbhd <= box * box * S
+        cmin, cmax = col.amin(dim=3), col.amax(dim=3)
+        wmin = -torch.nn.functional.max_pool2d(pad(-cmin, (b, b, b, b), value=-1e30), 2 * b + 1, stride=1)
+        wmax = torch.nn.functional.max_pool2d(pad(cmax, (b, b, b, b), value=-1e30), 2 * b + 1, stride=1)
+        assert bool((out >= wmin[..., None] - 1e-9).all()) and bool((out <= wmax[..., None] + 1e-9).all())
+        host = planes[:, r0 - b:r0 + R + b].cpu().numpy()
+        cin = col[:, r0 - b:r0 + R + b].cpu().numpy()
+        want = oracle.filter_pass(host, oracle.make_desc(W, 2 * b + R, S, box=box, row_begin=b, row_end=b + R,
+                                                         policy=oracle.DEGEN_EPS), colour_in=cin, debug=False)["colour"]
+        got = out[:, r0:r0 + R].cpu().numpy()
+        assert rel_l2(got, want[:, b:b + R]) <= REL_L2_BAR
+        moved = max(moved, rel_l2(got, cin[:, b:b + R]))
+        col = out
+    assert moved > 1e-3   # the passes did something on these rows
+
+
+def test_config4_shape_full_rank_slab_3840x276x32(ctx, hipmod, oracle):
+    """BASELINE configs[3]: 3840x2160x32 spp row-tiled over 8 GPUs -- the buffer of an interior rank: 270 owned rows
+    plus 3 halo rows either side (slabs.slab_for(2160, 8, 4, 3)), filtered as that rank filters it: determinism,
+    neighbourhood bounds, hull bounds, halo rows untouched, and the oracle on one full-width owned row."""
+    import torch
+    from raytracer_rpf_amd import slabs
+    W, S, b = 3840, 32, 3
+    slab = slabs.slab_for(2160, 8, 4, b)
+    H, rb, re = slabs.buffer_rows(slab)
+    assert (H, rb, re) == (276, 3, 273)
+    dev = torch.device("cuda", 0)
+    planes = fb.synth_planes(W, H, S, row0=slab.row0 - slab.halo_top, xp=fb.torch_backend(dev), mode="smooth",
+                             sigma_f=0.05, sigma_c=1e-4).contiguous()
+    col0 = planes[2:5].to(torch.float64).contiguous()
+    desc = hipmod.make_desc(W, H, S, row_begin=rb, row_end=re, policy=hipmod.DEGEN_EPS)
+    stream = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for _ in range(2):
+        c = col0.clone()
+        ctx.filter_device(desc, planes.data_ptr(), c.data_ptr(), stream)
+        outs.append(c)
+    torch.cuda.synchronize()
+    out = outs[0]
+    assert torch.equal(out, outs[1])
+    cnt = ctx.counters()
+    assert cnt.samples_filtered == 270 * W * S and cnt.nonfinite_pixels == 0 and S <= cnt.max_nbhd <= 49 * S
+    assert cnt.sum_nbhd > 20 * S * W * 270          # the large-neighbourhood regime (four-wave kernels)
+    assert torch.equal(out[:, :rb], col0[:, :rb]) and torch.equal(out[:, re:], col0[:, re:])
+    pad = torch.nn.functional.pad
+    cmin, cmax = col0.amin(dim=3), col0.amax(dim=3)
+    wmin = -torch.nn.functional.max_pool2d(pad(-cmin, (b, b, b, b), value=-1e30), 2 * b + 1, stride=1)
+    wmax = torch.nn.functional.max_pool2d(pad(cmax, (b, b, b, b), value=-1e30), 2 * b + 1, stride=1)
+    assert bool((out >= wmin[..., None] - 1e-9).all()) and bool((out <= wmax[..., None] + 1e-9).all())
+    r0 = 140
+    host = planes[:, r0 - b:r0 + 1 + b].cpu().numpy()
+    want = oracle.filter_pass(host, oracle.make_desc(W, 2 * b + 1, S, box=7, row_begin=b, row_end=b + 1,
+                                                     policy=oracle.DEGEN_EPS), debug=False)["colour"][:, b:b + 1]
+    assert rel_l2(out[:, r0:r0 + 1].cpu().numpy(), want) <= REL_L2_BAR
+
+
+def test_exactly_independent_table_at_non_power_of_two_n(ctx, hipmod, oracle):
+    """One pixel, S = N = 15, B = 3: columns binned (5,5,5) against columns binned (9,3,3) are EXACTLY independent
+    (J_ij * 15 == hx_i * hy_j).  For N a power of two mi.cpp returns an exact 0 for such a table; at N = 15 its quotients
+    pXY / (pX * pY) round to 1 +- 2.2e-16 and it returns rounding residue instead.  Recorded behaviour:
+      REF_ABORT  oracle (= the reference statement by statement): |MI| ~ 1e-17 residue feeds rpf.cpp:465/470, the
+                 weights are arbitrary; the HIP path evaluates MI over integers and returns exactly 0 for the same
+                 pairs (documented deviation, DESIGN.md section 5) -- everything discrete is identical;
+      EPS        both sides return exactly 0 (the residue contract) and every weight agrees to rounding."""
+    W, H, S = 1, 1, 15
+    a = np.repeat([0.0, 0.5, 1.0], 5)                                   # bins (5,5,5)
+    b = np.concatenate([np.tile([0.0] * 3 + [0.5] + [1.0], 3)])         # bins (9,3,3), independent of a
+    rng = np.random.default_rng(3)
+    planes = np.empty((19, H, W, S), np.float32)
+    for c in range(19):
+        planes[c, 0, 0] = rng.permutation(15) / 14.0                    # generic columns
+    planes[5, 0, 0], planes[6, 0, 0] = a, b                             # r0, r1
+    planes[7, 0, 0], planes[8, 0, 0] = b, a                             # f0, f1
+    pa, pb = oracle.pair_table()
+    ref = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7))
+    got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S), box=7, allow_nonfinite=True)
+    indep = [i for i in range(96) if (pa[i], pb[i]) in ((7, 5), (8, 6))]
+    assert len(indep) == 2
+    assert (np.abs(ref["mi"][0, 0, indep]) < 1e-15).all() and (got["mi"][0, 0, indep] == 0).all()
+    for k in ("nbhd_size", "member_hash", "bin_hash"):
+        assert (got[k] == ref[k]).all()
+    assert np.array_equal(got["mean"], ref["mean"]) and np.array_equal(got["stddev"], ref["stddev"])
+    others = [i for i in range(96) if i not in indep]
+    np.testing.assert_allclose(got["mi"][0, 0, others], ref["mi"][0, 0, others], rtol=0, atol=1e-11)
+    e_ref = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7, policy=oracle.DEGEN_EPS))
+    e_got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS), box=7)
+    assert (e_ref["mi"][0, 0, indep] == 0).all() and (e_got["mi"][0, 0, indep] == 0).all()
+    check_pass(e_got, e_ref)
+
+
 @pytest.mark.parametrize("W,H,S,box,mode,sf,sc", [
     (24, 16, 8, 7, "clustered", 1e-3, 0.01),
     (24, 16, 8, 7, "smooth", 0.05, 1e-4),
@@ -100,10 +232,9 @@ def test_ref_abort_status_on_constant_feature(ctx, hipmod, oracle):
     # the same buffer completes under the EPS policy, identically on both sides
     got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS), box=7)
     want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7, policy=oracle.DEGEN_EPS))
-    # D terms that are pure rounding residue (~1e-14: the device tabulates k ln k in 2^-44 fixed point, the
-    # oracle sums log() terms) are divided by (residue + eps=1e-10) under EPS: the ratio inherits
-    # residue / eps ~ 1e-4 of relative noise.  The colours still agree to the rel-L2 bar.
-    check_pass(got, want, ab_rtol=5e-3)
+    # EPS residue contract (oracle/rpf_oracle.c mi_scratch, rpf_kernels.hip stage 3b): an MI whose fixed-point integer
+    # form lies inside the table's rounding band is exactly 0 on both sides, so alpha / beta / W_r_c agree to rounding
+    check_pass(got, want)
     assert np.isfinite(got["colour"]).all()
 
 
@@ -162,7 +293,7 @@ def test_multi_pass_with_size_binning(ctx, hipmod, oracle):
     assert rel_l2(srgb.astype(np.float64), planes[2:5].astype(np.float64)) > 1e-3
 
 
-@pytest.mark.parametrize("boxes,rows", [((7,), None), ((7, 5), None), ((5, 7, 5), (6, 140)), ((7,), (20, 41))])
+@pytest.mark.parametrize("boxes,rows", [((7,), None), ((7, 5), None), ((5, 7, 5), None), ((5,), (6, 140)), ((7,), (20, 41))])
 def test_host_entry_band_pipeline_equals_serial(ctx, hipmod, oracle, boxes, rows):
     """rpf_filter() on page-locked buffers (rpf_host_alloc) overlaps upload / filter / download over row bands; it
     must give bit-for-bit what the serial sequence (RPF_FLAG_NO_OVERLAP, and any pageable buffer) gives"""
@@ -232,19 +363,25 @@ def test_more_shapes_vs_oracle(ctx, hipmod, oracle, W, H, S, box):
     planes = fb.synth_planes(W, H, S, seed=23, sigma_f=0.02, sigma_c=0.01, mode="clustered")
     got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS), box=box)
     want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=box, policy=oracle.DEGEN_EPS))
-    check_pass(got, want, ab_rtol=1e-6)
+    check_pass(got, want)
 
 
 @pytest.mark.parametrize("S,nw", [(16, "4"), (32, "1"), (64, "1")])
-def test_waves_per_pixel_variants_agree(ctx, hipmod, oracle, monkeypatch, S, nw):
-    """large neighbourhoods run four waves per pixel by default (32 spp and up), one otherwise; RPF_NW forces the
-    other variant: both must reproduce the oracle's discrete outcomes exactly"""
+def test_waves_per_pixel_variants_agree(ctx, hipmod, oracle, S, nw):
+    """large neighbourhoods run four waves per pixel by default (32 spp and up), one otherwise; the per-context option
+    "waves_per_pixel" forces the other variant: both must reproduce the oracle's discrete outcomes exactly"""
     W, H = 11, 9
     planes = fb.synth_planes(W, H, S, seed=31 + S, sigma_f=0.05, sigma_c=1e-4, mode="smooth")
     want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7))
-    monkeypatch.setenv("RPF_NW", nw)
-    got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S), box=7)
+    ctx.set_option("waves_per_pixel", int(nw))
+    try:
+        got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S), box=7)
+        assert ctx.counters().options_active == 1
+    finally:
+        ctx.set_option("waves_per_pixel", 0)
     check_pass(got, want)
+    with pytest.raises(hipmod.RpfError):
+        ctx.set_option("no_such_option", 1)
 
 
 def test_small_neighbourhood_paths_vs_oracle(ctx, hipmod, oracle):
@@ -256,11 +393,21 @@ def test_small_neighbourhood_paths_vs_oracle(ctx, hipmod, oracle):
         planes = fb.synth_planes(W, H, S, seed=31, sigma_f=sf, sigma_c=0.01, mode="smooth")
         got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS), box=7)
         want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7, policy=oracle.DEGEN_EPS))
-        check_pass(got, want, ab_rtol=5e-3)
+        check_pass(got, want)
         nb = want["nbhd_size"]
         seen_tiny |= bool((nb <= 64).any())
         seen_deep |= bool(((nb > 64) & (nb <= 128)).any())
     assert seen_tiny and seen_deep
+
+
+def test_multi_pass_on_a_sub_slab_is_refused(ctx, hipmod):
+    """the reference filters the whole film every pass (rpf.cpp:732); a strict sub-slab with n_box > 1 would read
+    unfiltered halo colours in pass 2, so the ABI refuses it (one pass per call + halo exchange, or rpf_filter_multi)"""
+    planes = np.zeros((19, 12, 4, 2), np.float32)
+    with pytest.raises(hipmod.RpfError) as e:
+        ctx.filter(planes, hipmod.make_desc(4, 12, 2, boxes=(7, 5), row_begin=3, row_end=9))
+    assert e.value.status == hipmod.E_BADARG and "halo" in str(e.value)
+    ctx.filter(planes + 1, hipmod.make_desc(4, 12, 2, boxes=(7,), row_begin=3, row_end=9, policy=hipmod.DEGEN_EPS))
 
 
 def test_badarg_and_unsupported(ctx, hipmod):
@@ -288,7 +435,7 @@ def test_gpu_reproduces_committed_fixtures(ctx, hipmod, name):
     _, H, W, S = planes.shape
     got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, policy=int(g["policy"])), box=int(g["box"]))
     want = {k: g[k] for k in ("nbhd_size", "member_hash", "bin_hash", "mean", "stddev", "mi", "alpha", "beta", "wrc", "colour")}
-    check_pass(got, want, ab_rtol=5e-3 if "eps" in name else 1e-9)
+    check_pass(got, want)
     assert got["nonfinite_pixels"] == int(g["nonfinite_pixels"])
 
 
@@ -339,9 +486,48 @@ def test_host_plane_film_producer_equals_sampling_film(hipmod, oracle):
     assert rel_l2(srgb.astype(np.float64), c) <= REL_L2_BAR
 
 
+def test_host_mirror_per_box_calls_carry_doubles(hipmod, oracle):
+    """the reference's own call shape: one ApplyRPFFilter(film, 16, box) per box size on the same film (rpf.cpp:767-775).
+    The film's colours are doubles (sd.h:205-208) and stay doubles across the boundary (rpf_filter_ex), so two calls
+    {7}, {5} equal ONE call with the box list {7, 5} bit for bit, and the oracle's two-pass chain to rounding."""
+    lib = C.CDLL(os.path.join(os.path.dirname(hipmod.LIB_PATH), "librpf_host.so"))
+    W, H, S = 13, 9, 8
+    planes = fb.synth_planes(W, H, S, seed=16, sigma_f=1e-3, sigma_c=0.01, mode="clustered")
+    boxes = (C.c_int32 * 2)(7, 5)
+    err = C.create_string_buffer(256)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    per_box, one_call = fb.planes_to_aos(planes), fb.planes_to_aos(planes)
+    st = lib.rpf_host_apply_filter_aos(vp(per_box), None, W, H, S, boxes, 2, 0x100, 1, 0, None, err, 256)
+    assert st == 0, err.value
+    st = lib.rpf_host_apply_filter_aos(vp(one_call), None, W, H, S, boxes, 2, 0, 1, 0, None, err, 256)
+    assert st == 0, err.value
+    assert np.array_equal(per_box, one_call)
+    c = None
+    for box in (7, 5):
+        c = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=box, policy=1), colour_in=c, debug=False)["colour"]
+    got = np.transpose(per_box[..., 2:5], (3, 1, 0, 2))
+    assert rel_l2(got, c) <= 1e-9
+    assert np.abs(got - got.astype(np.float32)).max() > 0     # genuinely doubles, not fp32-rounded colours
+
+
+def test_rpfb_fixture_through_the_hip_path(ctx, hipmod):
+    """a committed on-disk feature buffer (.rpfb: header + planes + ray weights) loaded and filtered with
+    the box list {7, 5}; expected values are the oracle's (tests/golden/make_golden.py rpfb)"""
+    planes, rw = fb.load_rpfb(os.path.join(GOLD, "clustered_10x8x8.rpfb"))
+    g = np.load(os.path.join(GOLD, "clustered_10x8x8_expected.npz"))
+    _, H, W, S = planes.shape
+    assert (W, H, S) == (10, 8, 8) and rw is not None
+    desc = hipmod.make_desc(W, H, S, boxes=tuple(int(b) for b in g["boxes"]), policy=int(g["policy"]))
+    srgb, prgb, st, c64 = ctx.filter(planes, desc, ray_weight=rw, want_colour64=True)
+    assert st == hipmod.OK
+    assert rel_l2(c64, g["colour"]) <= 1e-9
+    assert rel_l2(srgb.astype(np.float64), g["colour"]) <= REL_L2_BAR
+    assert rel_l2(prgb.astype(np.float64), g["pixel_rgb"]) <= REL_L2_BAR
+    assert rel_l2(c64, planes[2:5].astype(np.float64)) > 1e-3
+
+
 @pytest.mark.parametrize("W,H,S,mode,sf,sc,R", [
     (1920, 1080, 8, "clustered", 1e-3, 0.01, 3),   # BASELINE configs[1]
-    (3840, 96, 32, "smooth", 0.05, 1e-4, 1),       # configs[3], one rank's slab cut short: N ~ 1500 (four-wave kernel)
     (3840, 64, 32, "clustered", 1e-3, 0.01, 1),    # same shape, small neighbourhoods: several size classes per pass
     (1920, 48, 64, "smooth", 0.05, 1e-4, 1),       # 64 spp: N ~ 3000
 ])
@@ -415,7 +601,7 @@ def test_randomised_parity_sweep(ctx, hipmod, oracle):
         tag = (W, H, S, box, mode, sf, policy, beta)
         assert got["nonfinite_pixels"] == want["nonfinite_pixels"], tag
         if np.isfinite(want["colour"]).all():
-            check_pass(got, want, ab_rtol=5e-3 if policy == hipmod.DEGEN_EPS else 1e-9)
+            check_pass(got, want)
         else:
             for k in ("nbhd_size", "member_hash", "bin_hash"):
                 assert (got[k] == want[k]).all(), (k, tag)

@@ -103,6 +103,63 @@ def test_oracle_stage3_inputs_and_mi_equal_the_compiled_reference(oracle):
         assert np.array_equal(mi, r["mi"][y, x])
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "libref_mi.so")),
+                    reason="oracle/_ref/libref_mi.so not built (needs /root/reference)")
+def test_oracle_stage4a_distances_equal_the_compiled_reference(oracle):
+    """stage 4a (rpf.cpp:646-670): the oracle's three weighted squared distances of normalised sample pairs against
+    sumArray(multiplyArrays(squareArray(subtractArrays(.,.)), w)) composed from the compiled ops.h, bit for bit, on the
+    normalised rows and the alpha / beta of real pixels (incl. large-magnitude rows and NaN / inf weights)"""
+    from raytracer_rpf_amd import feature_buffer as fb
+    W, H, S, box = 9, 8, 8, 7
+    planes = fb.synth_planes(W, H, S, seed=13, sigma_f=1e-3, sigma_c=0.01, mode="clustered")
+    planes[10:13] += 700.0
+    r = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=box, n_threads=1))
+    rng = np.random.default_rng(9)
+    checked = 0
+    for (y, x) in ((4, 4), (0, 0), (7, 3), (2, 8)):
+        m, s = r["mean"][y, x], r["stddev"][y, x]
+        own = np.stack([oracle.ref_normalize(planes[:, y, x, i].astype(float), m, s) for i in range(S)])
+        others = np.stack([oracle.ref_normalize(planes[:, (y + dy) % H, (x + dx) % W, i].astype(float), m, s)
+                           for dy, dx, i in rng.integers(0, 4, size=(24, 3))])
+        for zi in own:
+            for zj in np.concatenate([own, others]):
+                got = oracle.weighted_sqdist(zi, zj, r["alpha"][y, x], r["beta"][y, x])
+                want = oracle.ref_weighted_sqdist(zi, zj, r["alpha"][y, x], r["beta"][y, x])
+                assert np.array_equal(got, want, equal_nan=True), (y, x, got, want)
+                checked += 1
+    # non-finite weights propagate identically
+    z = rng.normal(size=(2, 19))
+    for a in (np.array([np.nan, 1.0, 2.0]), np.array([np.inf, 0.0, -1.0])):
+        b = np.concatenate([a, rng.normal(size=9)])
+        assert np.array_equal(oracle.weighted_sqdist(z[0], z[1], a, b), oracle.ref_weighted_sqdist(z[0], z[1], a, b),
+                              equal_nan=True)
+    assert checked >= 1000
+
+
+def test_eps_residue_contract(oracle):
+    """EPS policy (documented deviation): an MI whose 2^-44 fixed-point integer form lies inside the table's rounding
+    band is exactly 0.  Constructed exactly-independent 3x3 tables at N = 12 (not a power of two): the reference's own
+    value (REF_ABORT: mi.cpp statement by statement) is rounding residue of either sign or an accidental 0; under EPS
+    every such pair is 0 and the weights are the clean 0 / (0 + 0 + eps) limits."""
+    # 12 samples, x in 3 bins (4,4,4), y in 2 bins (6,6): J_ij = 2 on every occupied cell -> J*N == hx*hy
+    x = np.repeat([0.0, 0.5, 1.0], 4)
+    y = np.tile([0.0, 0.0, 1.0, 1.0], 3)
+    assert abs(oracle.mi(x, y)) < 1e-15          # the reference: residue or 0, never a real dependence
+    z = np.zeros((12, 19))
+    z[:, 5], z[:, 6] = x, y                       # random parameters
+    z[:, 0], z[:, 1] = y, x                       # pFilm
+    for k in range(12):
+        z[:, 7 + k] = np.roll(x, 0) if k % 2 == 0 else y   # features exactly independent of r and p where they differ
+    for c in range(3):
+        z[:, 2 + c] = y if c % 2 == 0 else x
+    a_eps, b_eps, w_eps, mi_eps = oracle.cf_weights(z, policy=oracle.DEGEN_EPS)
+    a_ref, b_ref, w_ref, mi_ref = oracle.cf_weights(z, policy=oracle.DEGEN_REF_ABORT)
+    indep = np.abs(mi_ref) < 1e-12
+    assert indep.any() and (mi_eps[indep] == 0).all()
+    assert np.array_equal(mi_eps[~indep], mi_ref[~indep])   # real dependences are untouched by the contract
+    assert np.isfinite(a_eps).all() and np.isfinite(b_eps).all() and np.isfinite(w_eps)
+
+
 @pytest.mark.parametrize("name", ["e2e_clustered_12x10x8_box7", "e2e_smooth_10x8x8_box7",
                                   "e2e_clustered_8x6x16_box5", "e2e_constnormal_8x6x8_box7_eps"])
 def test_oracle_reproduces_committed_end_to_end_fixtures(oracle, name):

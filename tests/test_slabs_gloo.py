@@ -72,3 +72,7 @@ def test_partition_arithmetic():
     assert (s.halo_top, s.halo_bottom) == (0, 3) and slabs.buffer_rows(s) == (273, 0, 270)
     s = slabs.slab_for(2160, 8, 4, 3)
     assert slabs.buffer_rows(s) == (276, 3, 273)
+    # a slab thinner than the halo its neighbours need cannot be served from owned rows: rejected, not silently wrong
+    with pytest.raises(ValueError):
+        slabs.slab_for(40, 8, 3, 27)   # box 55 needs 27 halo rows, 40/8 = 5 rows per rank
+    assert slabs.slab_for(40, 1, 0, 27) == slabs.Slab(0, 40, 0, 0)
