@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--fast-weights", action="store_true", help="opt-in fp32 pair weights (RPF_FLAG_FAST_WEIGHTS)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="rpf_set_option override (diagnostics: stage_mask, binning, waves_per_pixel, table_in_lds, lds_pad)")
+    ap.add_argument("--allow-nonfinite", action="store_true", help="profiling variants whose results are wrong on purpose")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank) is the measured path; gloo lets several ranks share one GPU to "
@@ -146,7 +147,7 @@ def main():
     def step():
         colour.copy_(colour0)                                   # the pass input (unfiltered colours)
         slabs.exchange_halo(colour, slab, rank, world)          # RCCL neighbour exchange of the colour halo
-        ctx.filter_device(desc, planes.data_ptr(), colour.data_ptr(), stream)
+        ctx.filter_device(desc, planes.data_ptr(), colour.data_ptr(), stream, allow_nonfinite=args.allow_nonfinite)
         kernel_ms.append(ctx.counters().filter_kernel_ms)
 
     def fence():

@@ -439,59 +439,168 @@ __device__ __forceinline__ void bins_stage(const PassParams &p, const double *sS
     }
 }
 
-// One group of G (3 or 4) joint histograms of one anchor column, straight-line: histogram u bins (anchor, partner
-// cols[u]).  Slots kk < KD-1 are full by definition of KD (= ceil(n/64)), so only the last slot carries the hole mask:
-// `last_ok` lanes exist, the others aim a +0 atomic at `hole`.  FULL = false (large neighbourhoods, KD = K): every
-// slot carries its own mask (lane + 64*kk < n).
-//
-// MARGINALS.  sum_i T[hx_i] of a column is needed once per column (19 of them).  Building 19 more histograms for that
-// is the most expensive way to get it: a marginal has only B cells, so the 64 lanes of an increment pile onto a handful
-// of addresses and same-address LDS atomics serialise (~1.8 cycles per lane, profiles/r01_lds_atomic_microbench.txt).
-// Instead the marginal counts are read off a joint histogram that is resident anyway, between its atomics and its
-// clearing store (one wave's LDS operations execute in order): hy_j = sum_i J[i][j] (column sums: the partner's
-// marginal) and hx_i = sum_j J[i][j] (row sums: the anchor's).  MARG bit 0: column sums of every histogram of the group
-// -> accm[u]; bit 1 (G == 3 only): row sums of histogram 0 -> accm[3].  Counts are integers: same totals, bit for bit.
-//   HALF (B <= 32): lane = (h, j), h = lane >> 5 takes every other row / column, the two halves meet in one
-//   v_permlane32_swap; NIT = compile-time trip count (>= ceil(B/2)), out-of-range steps re-read a valid cell and add 0.
-//   !HALF (B <= 64): lane = j, run-time loop over all B rows.
-template <bool HALF, int NIT, bool ROWS>
+// ---- marginal counts off a resident joint histogram ------------------------------------------------------------
+// sum_i T[hx_i] of a column is needed once per column (19 of them).  Building 19 more histograms for that is the most
+// expensive way to get it (a marginal has only B cells: 64 lanes pile onto a handful of addresses).  Instead the
+// counts are read off a joint histogram that is resident anyway, between its atomics and its clearing store (one
+// wave's LDS operations execute in order): hy_j = sum_i J[i][j] (column sums: the partner's marginal), hx_i = sum_j
+// J[i][j] (row sums: the anchor's).  Counts are integers: same totals, bit for bit.  B <= 32: lane = (h, j), h = lane
+// >> 5 takes every other row / column, the two halves meet in one v_permlane32_swap; NIT = compile-time trip count
+// (>= ceil(B/2)).
+template <int NIT, bool ROWS>
 __device__ __forceinline__ uint32_t marginal_counts(const uint32_t *sHist, int lane, int B) {
     uint32_t tot = 0u;
-    if constexpr (HALF) {
-        const int j = lane & 31, h = lane >> 5;
-        const int jj = min(j, B - 1);
-        uint32_t v[NIT];
+    const int j = lane & 31, h = lane >> 5;
+    uint32_t v[NIT];
+    if constexpr (!ROWS) {
+        // column sums: rows i = h, h + 2, ... of column j.  No masks: a row index past B lands in the cleared cells
+        // behind the live histogram (the clearing stores of every ZN class cover 2 * NIT * B cells, and nothing
+        // increments them), lanes j >= B read a neighbouring row and are dropped below.
+        const uint32_t *col = sHist + h * B + j;
 #pragma unroll
-        for (int t = 0; t < NIT; ++t) {
-            const int i = min(2 * t + h, B - 1);
-            v[t] = sHist[ROWS ? jj * B + i : i * B + jj];
-        }
+        for (int t = 0; t < NIT; ++t) v[t] = col[2 * t * B];
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) tot += v[t];
+    } else {
+        const int jj = min(j, B - 1);
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) v[t] = sHist[jj * B + min(2 * t + h, B - 1)];
 #pragma unroll
         for (int t = 0; t < NIT; ++t) tot += (2 * t + h < B) ? v[t] : 0u;
-        tot = xl::exch32<xl::OpSum>(tot, tot);          // both halves now hold the full count of bin j
-        tot = (j < B && h == 0) ? tot : 0u;            // one lane per bin contributes T[count] (T[0] == 0)
-    } else {
-        const int jj = min(lane, B - 1);
-#pragma unroll 4
-        for (int i = 0; i < B; ++i) tot += sHist[ROWS ? jj * B + i : i * B + jj];
-        tot = (lane < B) ? tot : 0u;
     }
-    return tot;
+    tot = xl::exch32<xl::OpSum>(tot, tot);          // both halves now hold the full count of bin j
+    return (j < B && h == 0) ? tot : 0u;            // one lane per bin contributes T[count] (T[0] == 0)
 }
 
-template <int KD, int KW, int ZN, int G, bool FULL, int PACK5, int MARG>
-__device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, const uint64_t *ttab,
-                                         int lane, int n, int B, const int (&cols)[4], const uint32_t (&akey)[KD],
-                                         bool last_ok, uint32_t hole, int cells, uint64_t (&acc4)[4], uint64_t (&accm)[4]) {
-    static_assert(!(MARG & 2) || G == 3, "the anchor's row sums ride in the free fourth slot of a three-histogram group");
-    constexpr bool HALF = KD <= 13;                                   // K <= 13: N <= 832, B <= 28
-    constexpr int NIT = !FULL ? 14 : (ZN == 1 ? 8 : (ZN == 3 ? 9 : (ZN == 4 ? 10 : 11))); // B <= 16 / 17 / 19 / 22 (28 when !FULL)
-    uint32_t old[2][KD];
-    uint32_t mcnt[2], rcnt = 0u;
-    const uint32_t one = 1u, last_inc = last_ok ? 1u : 0u;
-    auto slot_ok = [&](int kk) -> bool { return FULL ? (kk < KD - 1 ? true : last_ok) : (lane + kWave * kk < n); };
+// D[c] through a 32-bit byte offset from the (wave-uniform) table base: scalar base + vector offset addressing
+__device__ __forceinline__ uint64_t dlook(const uint64_t *dtab, uint32_t c) {
+    return *reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(dtab) + (c << 3));
+}
+
+// ---- one-wave kernels (K <= 8, 3 <= KD): PARTNER-major histogram groups ---------------------------------------
+// All joint histograms of ONE partner column, one per anchor: the partner's bin ids are unpacked once for the
+// whole group and every anchor's (bin * B * 4 + histogram base) sits in registers (akey4[anchor][slot], formed once per
+// pixel), so the address of an increment is a single v_lshl_add.  NA = anchors of the group (7 for a feature partner:
+// r0 r1 p0 p1 c0 c1 c2; 4 for a colour partner: r0 r1 p0 p1).  Slots kk < KD-1 are full by definition of KD
+// (= ceil(n/64)), so only the last slot carries the hole mask: `last_ok` lanes exist, the others aim a +0 atomic at `hole`.
+// Histogram u+1's atomics are queued before the D look-ups of histogram u are consumed; the clearing store sits right
+// behind the atomics.  MARG bit 0: the partner's marginal from the column sums of histogram 0 -> macc; bit 1: the
+// anchors' marginals from the row sums of every histogram of the group -> racc[u].
+template <int KD, int KW, int ZN, int NA, int NAMAX, int PACK5, int MARG>
+__device__ __forceinline__ void mi_pgroup(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, const uint64_t *ttab,
+                                          int lane, int B, int pcol, const uint32_t (&akey4)[NAMAX][KD], bool last_ok,
+                                          uint32_t hole4, int cells, uint64_t (&acc)[8], uint64_t &macc, uint64_t (&racc)[4]) {
+    constexpr int NIT = ZN == 1 ? 8 : (ZN == 3 ? 9 : (ZN == 4 ? 10 : 11)); // B <= 16 / 17 / 19 / 22
+    static_assert(NA <= 8 && (!(MARG & 2) || NA <= 4), "slot budget of the reductions");
+    uint32_t bin4[KD];
+    {
+        BinIds<KW, PACK5> w;
+        load_bins<KD, KW, PACK5>(sBinW, pcol, lane, w);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) accm[u] = 0ull;
+        for (int kk = 0; kk < KD; ++kk) bin4[kk] = w.get(kk) << 2;
+    }
+    char *hbase = reinterpret_cast<char *>(sHist);
+    uint32_t old[2][KD];
+    uint32_t mcnt = 0u, rcnt[2] = {0u, 0u};
+    const uint32_t last_inc = last_ok ? 1u : 0u;
+#pragma unroll
+    for (int u = 0; u <= NA; ++u) {
+        if (u < NA) {
+#pragma unroll
+            for (int kk = 0; kk < KD; ++kk) {
+                uint32_t off = akey4[u][kk] + bin4[kk];                                  // mi.cpp:39 (x 4 bytes)
+                if (kk == KD - 1) off = last_ok ? off : hole4;
+                old[u & 1][kk] = atomicAdd(reinterpret_cast<uint32_t *>(hbase + off), kk == KD - 1 ? last_inc : 1u);
+            }
+            if constexpr (MARG != 0) {
+                if ((MARG & 2) || u == 0) {
+                    wsync(); // the counts other lanes' atomics left are read below (in-order LDS: program order only)
+                    if constexpr (MARG & 1) if (u == 0) mcnt = marginal_counts<NIT, false>(sHist, lane, B);
+                    if constexpr ((MARG & 2) != 0) rcnt[u & 1] = marginal_counts<NIT, true>(sHist, lane, B);
+                    wsync();
+                }
+            }
+            zero_cells<ZN>(sHist, cells, lane);
+        }
+        if (u >= 1) {
+            uint64_t d[KD];
+#pragma unroll
+            for (int kk = 0; kk < KD; ++kk) d[kk] = dlook(dtab, old[(u - 1) & 1][kk]);
+            uint64_t a = last_ok ? d[KD - 1] : 0ull;
+#pragma unroll
+            for (int kk = 0; kk < KD - 1; ++kk) a += d[kk];
+            acc[u - 1] = a;
+            if constexpr ((MARG & 2) != 0) racc[u - 1] = dlook(ttab, rcnt[(u - 1) & 1]);
+        }
+    }
+    if constexpr (MARG & 1) macc = dlook(ttab, mcnt);
+#pragma unroll
+    for (int u = NA; u < 8; ++u) acc[u] = 0ull;
+}
+
+// The partner-major MI stage.  Anchor a: 0..1 = r0, r1; 2..3 = p0, p1; 4..6 = c0..c2.  Pair index = position in
+// ComputeCFWeights' call order (rpf.cpp:416-442).  Marginal sums sHXf: every partner's from its own group (f0..f11,
+// c0..c2 are all partners), r0 r1 p0 p1 from the row sums of the c0 group's four histograms.
+template <int KD, int KW, int ZN, int PACK5>
+__device__ __forceinline__ void mi_stage_pm(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, const uint64_t *ttab,
+                                            uint64_t *sHXf, uint64_t *sPairF, int lane, int n, int B) {
+    constexpr int NA = 7;
+    const int ncell2 = B * B;
+    const bool last_ok = (lane + kWave * (KD - 1)) < n;                 // does this lane's last sample slot exist?
+    const uint32_t hole4 = (uint32_t)min(lane, ncell2 - 1) << 2;        // harmless, spread-out targets of the +0 atomics
+    zero_cells<ZN>(sHist, ncell2, lane);
+    uint32_t akey4[NA][KD];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const int acol = a < 2 ? kColR + a : (a < 4 ? kColP + (a - 2) : kColC + (a - 4));
+        BinIds<KW, PACK5> w;
+        load_bins<KD, KW, PACK5>(sBinW, acol, lane, w);
+#pragma unroll
+        for (int kk = 0; kk < KD; ++kk) akey4[a][kk] = w.get(kk) * (uint32_t)(B * 4);
+    }
+    auto pair_index = [&](int a, int i) { // anchor a, partner i (0..11 features, 12..14 colours)
+        return a < 4 ? (i < 12 ? i * 4 + a : 48 + (i - 12) * 16 + a) : 48 + (a - 4) * 16 + 4 + i;
+    };
+#pragma unroll 1
+    for (int i = 0; i < kNFeat; ++i) { // feature partners: 7 histograms each
+        uint64_t acc[8], macc = 0ull, racc[4];
+        mi_pgroup<KD, KW, ZN, 7, NA, PACK5, 1>(sBinW, sHist, dtab, ttab, lane, B, kColF + i, akey4, last_ok, hole4, ncell2, acc, macc, racc);
+        acc[7] = macc; // the free eighth slot carries the partner's marginal
+        const uint64_t tot = xl::reduce8<xl::OpSum>(acc, lane);
+        if ((lane & 7) == 0) {
+            const int sl = xl::slot8(lane);
+            if (sl < 7) sPairF[pair_index(sl, i)] = tot;
+            else sHXf[kColF + i] = tot;
+        }
+    }
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) { // colour partners: 4 histograms each (anchors r0 r1 p0 p1)
+        uint64_t acc[8], macc = 0ull, racc[4] = {0ull, 0ull, 0ull, 0ull};
+        if (c == 0) mi_pgroup<KD, KW, ZN, 4, NA, PACK5, 3>(sBinW, sHist, dtab, ttab, lane, B, kColC, akey4, last_ok, hole4, ncell2, acc, macc, racc);
+        else mi_pgroup<KD, KW, ZN, 4, NA, PACK5, 1>(sBinW, sHist, dtab, ttab, lane, B, kColC + c, akey4, last_ok, hole4, ncell2, acc, macc, racc);
+        acc[7] = macc;
+        if (c == 0) { acc[4] = racc[0]; acc[5] = racc[1]; acc[6] = racc[2]; }
+        const uint64_t tot = xl::reduce8<xl::OpSum>(acc, lane);
+        const uint64_t r3 = (c == 0) ? xl::allreduce<xl::OpSum>(racc[3]) : 0ull; // wave-uniform branch
+        if ((lane & 7) == 0) {
+            const int sl = xl::slot8(lane);
+            if (sl < 4) sPairF[pair_index(sl, 12 + c)] = tot;
+            else if (sl == 7) sHXf[kColC + c] = tot;
+            else if (c == 0) sHXf[sl == 4 ? kColR : (sl == 5 ? kColR + 1 : kColP)] = tot;
+        }
+        if (c == 0 && lane == 0) sHXf[kColP + 1] = r3;
+    }
+}
+
+// ---- large-neighbourhood kernels (K >= 13): ANCHOR-major groups of G (3 or 4) histograms ----------------------------
+// For marginals (JOINT = false) histogram u bins column cols[u]; for joints it bins (anchor, partner cols[u]).  Every
+// slot carries its own mask (lane + 64*kk < n): masked lanes aim a +0 atomic at `hole`.
+template <int KD, int KW, int G, int PACK5, bool JOINT>
+__device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, int lane, int n,
+                                         const int (&cols)[4], const uint32_t (&akey)[KD], uint32_t hole, int cells,
+                                         uint64_t (&acc4)[4]) {
+    uint32_t old[2][KD];
+    auto slot_ok = [&](int kk) -> bool { return lane + kWave * kk < n; };
 #pragma unroll
     for (int u = 0; u <= G; ++u) {
         if (u < G) {
@@ -499,22 +608,12 @@ __device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist,
             load_bins<KD, KW, PACK5>(sBinW, cols[u], lane, w);
 #pragma unroll
             for (int kk = 0; kk < KD; ++kk) {
-                uint32_t key = w.get(kk) + akey[kk];                         // mi.cpp:39
-                if (FULL) {
-                    if (kk == KD - 1) key = last_ok ? key : hole;
-                    old[u & 1][kk] = atomicAdd(&sHist[key], kk == KD - 1 ? last_inc : one);
-                } else {
-                    const bool ok = slot_ok(kk);
-                    old[u & 1][kk] = atomicAdd(&sHist[ok ? key : hole], ok ? 1u : 0u);
-                }
+                uint32_t key = w.get(kk);
+                if (JOINT) key += akey[kk];                                  // mi.cpp:39
+                const bool ok = slot_ok(kk);
+                old[u & 1][kk] = atomicAdd(&sHist[ok ? key : hole], ok ? 1u : 0u);
             }
-            if constexpr (MARG != 0) {
-                wsync(); // the counts other lanes' atomics left are read below (in-order LDS: no wait, only program order)
-                if constexpr (MARG & 1) mcnt[u & 1] = marginal_counts<HALF, NIT, false>(sHist, lane, B);
-                if constexpr ((MARG & 2) != 0) if (u == 0) rcnt = marginal_counts<HALF, NIT, true>(sHist, lane, B);
-                wsync();
-            }
-            zero_cells<ZN>(sHist, cells, lane);
+            zero_cells<0>(sHist, cells, lane);
         }
         if (u >= 1) {
             uint64_t d[KD];
@@ -524,10 +623,8 @@ __device__ __forceinline__ void mi_group(const uint32_t *sBinW, uint32_t *sHist,
 #pragma unroll
             for (int kk = 0; kk < KD - 1; ++kk) a += slot_ok(kk) ? d[kk] : 0ull;
             acc4[u - 1] = a;
-            if constexpr (MARG & 1) accm[u - 1] = ttab[mcnt[(u - 1) & 1]];
         }
     }
-    if constexpr ((MARG & 2) != 0) accm[3] = ttab[rcnt];
 #pragma unroll
     for (int u = G; u < 4; ++u) acc4[u] = 0ull;
 }
@@ -689,22 +786,40 @@ __device__ __forceinline__ void mi_stage_tiny(const uint32_t *sBinW, uint32_t *s
     }
 }
 
-// NW > 1: the 25 histogram groups are dealt round-robin to the NW waves of the pixel; every wave has its own histogram
-// buffer and covers all n samples of its groups, so the stage needs no barrier.
-// Marginal sums (sHXf) come out of the joint histograms (mi_group, "MARGINALS"): the partners' from the groups of the
-// first anchor (r0: f0..f11 and c0..c2 are all partners there), the anchors' r0, r1, p0, p1 from the row sums of the
-// first histogram of their c-partner group.
-template <int KD, int KW, int ZN, bool FULL, int PACK5, int NW = 1>
-__device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, const uint64_t *ttab,
-                                         uint64_t *sHXf, uint64_t *sPairF, int lane, int n, int B, int wv = 0) {
+// Large neighbourhoods (K >= 13).  NW > 1: the 30 histogram groups (5 marginal + 25 joint) are dealt round-robin to
+// the NW waves of the pixel; every wave has its own histogram buffer and covers all n samples of its groups, so the
+// stage needs no barrier.  (These kernels sit at the register limit of 2 or 1 waves per SIMD: the marginal read-back
+// and the partner-major key registers of the one-wave kernels cost them spills, measured 305 -> 466 ms on a 4K x 32 spp slab.)
+template <int KD, int KW, int PACK5, int NW = 1>
+__device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, uint64_t *sHXf,
+                                         uint64_t *sPairF, int lane, int n, int B, int wv = 0) {
     int gi = 0; // running group number (wave-uniform)
     auto mine = [&]() { const bool m = (NW == 1) || (gi % NW) == wv; ++gi; return m; };
     const int ncell2 = B * B;
-    const bool last_ok = (lane + kWave * (KD - 1)) < n;     // does this lane's last sample slot exist?
-    const uint32_t hole2 = (uint32_t)min(lane, ncell2 - 1); // harmless, spread-out targets of the +0 atomics
-    zero_cells<ZN>(sHist, ncell2, lane);
+    const uint32_t hole1 = (uint32_t)min(lane, B - 1);      // harmless, spread-out targets of the +0 atomics
+    const uint32_t hole2 = (uint32_t)min(lane, ncell2 - 1);
+    zero_cells<0>(sHist, ncell2, lane);
     uint32_t akey[KD];
-    // joint histograms, grouped by an anchor column whose (bin * B) stays in registers
+#pragma unroll
+    for (int kk = 0; kk < KD; ++kk) akey[kk] = 0u;
+    // ---- marginals: sum_i T[hx_i] per column; 19 columns = 4 groups of 4 + one group of 3
+#pragma unroll 1
+    for (int c0 = 0; c0 < 16; c0 += 4) {
+        if (!mine()) continue;
+        uint64_t acc4[4];
+        const int cols[4] = {c0, c0 + 1, c0 + 2, c0 + 3};
+        mi_group<KD, KW, 4, PACK5, false>(sBinW, sHist, dtab, lane, n, cols, akey, hole1, B, acc4);
+        const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
+        if ((lane & 15) == 0) sHXf[c0 + xl::slot4(lane)] = tot;
+    }
+    if (mine()) {
+        uint64_t acc4[4];
+        const int cols[4] = {16, 17, 18, 18};
+        mi_group<KD, KW, 3, PACK5, false>(sBinW, sHist, dtab, lane, n, cols, akey, hole1, B, acc4);
+        const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
+        if ((lane & 15) == 0 && xl::slot4(lane) < 3) sHXf[16 + xl::slot4(lane)] = tot;
+    }
+    // ---- joint histograms, grouped by an anchor column whose (bin * B) stays in registers
     //   anchors 0..3 = r0, r1, p0, p1 with partners f0..f11, c0..c2 ; anchors 4..6 = c0..c2 with f0..f11
 #pragma unroll 1
     for (int g = 0; g < 7; ++g) {
@@ -721,29 +836,16 @@ __device__ __forceinline__ void mi_stage(const uint32_t *sBinW, uint32_t *sHist,
 #pragma unroll 1
         for (int i0 = 0; i0 < 12; i0 += 4) { // partners f0..f11
             if (!mine()) continue;
-            uint64_t acc4[4], accm[4];
+            uint64_t acc4[4];
             const int cols[4] = {kColF + i0, kColF + i0 + 1, kColF + i0 + 2, kColF + i0 + 3};
-            if (g == 0) { // wave-uniform: the first anchor's groups also deliver their partners' marginals
-                mi_group<KD, KW, ZN, 4, FULL, PACK5, 1>(sBinW, sHist, dtab, ttab, lane, n, B, cols, akey, last_ok, hole2, ncell2, acc4, accm);
-                const uint64_t mt = xl::reduce4<xl::OpSum>(accm);
-                if ((lane & 15) == 0) sHXf[kColF + i0 + xl::slot4(lane)] = mt;
-            } else {
-                mi_group<KD, KW, ZN, 4, FULL, PACK5, 0>(sBinW, sHist, dtab, ttab, lane, n, B, cols, akey, last_ok, hole2, ncell2, acc4, accm);
-            }
+            mi_group<KD, KW, 4, PACK5, true>(sBinW, sHist, dtab, lane, n, cols, akey, hole2, ncell2, acc4);
             const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
             if ((lane & 15) == 0) sPairF[pair_index(i0 + xl::slot4(lane))] = tot;
         }
-        if (g < 4 && mine()) { // partners c0..c2 (wave-uniform branch); slot 3 carries the anchor's own marginal
-            uint64_t acc4[4], accm[4];
+        if (g < 4 && mine()) { // partners c0..c2 (wave-uniform branch)
+            uint64_t acc4[4];
             const int cols[4] = {kColC, kColC + 1, kColC + 2, kColC + 2};
-            if (g == 0) mi_group<KD, KW, ZN, 3, FULL, PACK5, 3>(sBinW, sHist, dtab, ttab, lane, n, B, cols, akey, last_ok, hole2, ncell2, acc4, accm);
-            else mi_group<KD, KW, ZN, 3, FULL, PACK5, 2>(sBinW, sHist, dtab, ttab, lane, n, B, cols, akey, last_ok, hole2, ncell2, acc4, accm);
-            const uint64_t mt = xl::reduce4<xl::OpSum>(accm);
-            if ((lane & 15) == 0) {
-                const int sl = xl::slot4(lane);
-                if (sl == 3) sHXf[acol] = mt;
-                else if (g == 0) sHXf[kColC + sl] = mt;
-            }
+            mi_group<KD, KW, 3, PACK5, true>(sBinW, sHist, dtab, lane, n, cols, akey, hole2, ncell2, acc4);
             const uint64_t tot = xl::reduce4<xl::OpSum>(acc4);
             if ((lane & 15) == 0 && xl::slot4(lane) < 3) sPairF[pair_index(12 + xl::slot4(lane))] = tot;
         }
@@ -1329,10 +1431,10 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
     if constexpr (K >= KD_) {                                                                                \
         if constexpr (KD_ == 1) mi_stage_tiny<KW, PACK5>(sBinW, sHist, p.tfix, sHXf, sPairF, lane, n, B); /* B*B <= 64 */ \
         else if constexpr (KD_ == 2) mi_stage_deep<KD_, KW, 1, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); /* B*B <= 121 */ \
-        else if (B * B <= 256) mi_stage<KD_, KW, 1, true, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B); \
-        else if (B * B <= 320) mi_stage<KD_, KW, 3, true, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B); \
-        else if (B * B <= 384) mi_stage<KD_, KW, 4, true, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B); \
-        else mi_stage<KD_, KW, 2, true, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B);               \
+        else if (B * B <= 256) mi_stage_pm<KD_, KW, 1, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B); \
+        else if (B * B <= 320) mi_stage_pm<KD_, KW, 3, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B); \
+        else if (B * B <= 384) mi_stage_pm<KD_, KW, 4, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B); \
+        else mi_stage_pm<KD_, KW, 2, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B);               \
     }
             switch (kdyn) {
             case 1: RPF_MI_CASE(1) break;
@@ -1346,7 +1448,7 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
             }
 #undef RPF_MI_CASE
         } else {
-            mi_stage<K, KW, 0, false, PACK5, NW>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B, wv);
+            mi_stage<K, KW, PACK5, NW>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B, wv);
         }
     }
     bsync();
@@ -1520,12 +1622,10 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
                 for (int k = 0; k < 3; ++k) cj[k] = pc[k];
                 if constexpr (NW > 1) fetch17(j + kWave); // the next slot's gathers fly while this one is weighted
                 // straight-line over the kOwnBlock own samples (a missing one re-reads the last row and its weight is
-                // forced to 0) so their dependent chains interleave; the 17-term dot product runs as four partial sums.
-                // exp(-E) is +0 for E > 745.14 (below the smallest subnormal), and with sigma^2 = 0.002^2 / (1-W)^2 that
-                // is what nearly every cross pair gets: when every lane's exponent is beyond 746 the exp()
-                // evaluation is skipped (wave-uniform branch) -- the weights are the same +0 (a NaN exponent fails the
-                // comparison and takes the exp path, which propagates it); the accumulations still run, so a
-                // non-finite colour times 0 gives the reference's NaN.
+                // forced to 0) so their dependent chains interleave; the 17-term dot product runs as four partial sums
+                // (skipping exp() where every lane's exponent underflows was tried twice -- a wave-uniform branch per own
+                // sample, and one per sweep step over stored exponents: both spill 24 .. 140 registers at three waves per
+                // SIMD and run slower, 75.9 vs 69.8 ms)
 #pragma unroll
                 for (int ii = 0; ii < kOwnBlock; ++ii) {
                     const int i = i0 + ii;
@@ -1544,8 +1644,7 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
                     }
                     e0 = fma(ui[16], zj[16], e0);
                     const double E = (e0 + e1) + (e2 + e3);
-                    double w = 0.0;
-                    if (!__all(E > 746.0)) w = exp(-E);         // rpf.cpp:667-670
+                    double w = exp(-E);                         // rpf.cpp:667-670
                     w = live ? w : 0.0;
                     sw[ii] += w;                                // rpf.cpp:691
                     s0[ii] = fma(w, cj[0], s0[ii]);             // rpf.cpp:692 (raw neighbourhood colours)

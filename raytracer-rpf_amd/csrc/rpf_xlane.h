@@ -130,6 +130,19 @@ __device__ __forceinline__ T reduce4(const T (&a)[4]) {
     const T b0 = exch32<Op>(a[0], a[2]), b1 = exch32<Op>(a[1], a[3]);
     return allreduce_row<Op>(exch16<Op>(b0, b1));
 }
+// 8 accumulators -> lane holds total of slot 4*b5 + 2*b4 + b3
+__device__ __forceinline__ int slot8(int lane) { return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1); }
+template <class Op, class T>
+__device__ __forceinline__ T reduce8(const T (&a)[8], int lane) {
+    T b4[4], b2[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b4[i] = exch32<Op>(a[i], a[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b2[i] = exch16<Op>(b4[i], b4[i + 2]);
+    T v = exch_row<Op, kRowMirror, 8>(b2[0], b2[1], lane);
+    v = Op::f(v, dpp<kRowHalfMirror>(v));
+    return allreduce_bits10<Op>(v);
+}
 // 16 accumulators -> lane holds total of slot 8*b5 + 4*b4 + 2*b3 + b2 (b_k = bit k of the lane id)
 __device__ __forceinline__ int slot16(int lane) {
     return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librpf_hip.so")
+# RPF_HIP_LIB: load another build of the same ABI (profiling variants, scripts/ablate_mi.sh); default = the in-tree library
+LIB_PATH = os.environ.get("RPF_HIP_LIB") or os.path.join(_HERE, "lib", "librpf_hip.so")
 
 NDIM, NFEAT, NPAIR, MAX_BOXES = 19, 12, 96, 8
 OK, E_BADARG, E_HIP, E_NONFINITE, E_NOMEM, E_UNSUPPORTED, E_NODEVICE = range(7)
