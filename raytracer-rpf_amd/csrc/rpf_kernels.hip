@@ -40,6 +40,7 @@ namespace rpf {
 
 namespace {
 
+constexpr int kDHead = 128;   // entries of the D table the one-wave kernels keep in LDS
 constexpr int kTFixBits = 44; // T[k] = k ln k is tabulated as round(T * 2^44): exact integer sums, |T| < 2^15 * 2^44
 
 // MI pair table in ComputeCFWeights call order (rpf.cpp:416-442)
@@ -486,10 +487,16 @@ __device__ __forceinline__ uint64_t dlook(const uint64_t *dtab, uint32_t c) {
 // Histogram u+1's atomics are queued before the D look-ups of histogram u are consumed; the clearing store sits right
 // behind the atomics.  MARG bit 0: the partner's marginal from the column sums of histogram 0 -> macc; bit 1: the
 // anchors' marginals from the row sums of every histogram of the group -> racc[u].
-template <int KD, int KW, int ZN, int NA, int NAMAX, int PACK5, int MARG>
-__device__ __forceinline__ void mi_pgroup(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, const uint64_t *ttab,
+// D look-ups: the first kDHead entries of the table sit in LDS (1 KiB: costs no resident workgroup), which is where
+// nearly every look-up lands (a cell that holds >= kDHead of a neighbourhood's <= 512 samples is a degenerate pixel); the
+// 480 look-ups per pixel were the kernel's main load on the texture-address path.  A wave in which some count reaches
+// kDHead repeats the pixel's MI stage with the full table in global memory (one wave-uniform branch per pixel, outside the
+// straight-line histogram code: a branch per histogram cost 146 spilled registers).
+template <int KD, int KW, int ZN, int NA, int NAMAX, int PACK5, int MARG, bool DHEAD>
+__device__ __forceinline__ void mi_pgroup(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, const uint64_t *sDh, const uint64_t *ttab,
                                           int lane, int B, int pcol, const uint32_t (&akey4)[NAMAX][KD], bool last_ok,
-                                          uint32_t hole4, int cells, uint64_t (&acc)[8], uint64_t &macc, uint64_t (&racc)[4]) {
+                                          uint32_t hole4, int cells, uint64_t (&acc)[8], uint64_t &macc, uint64_t (&racc)[4],
+                                          uint32_t &mx) {
     constexpr int NIT = ZN == 1 ? 8 : (ZN == 3 ? 9 : (ZN == 4 ? 10 : 11)); // B <= 16 / 17 / 19 / 22
     static_assert(NA <= 8 && (!(MARG & 2) || NA <= 4), "slot budget of the reductions");
     uint32_t bin4[KD];
@@ -524,8 +531,17 @@ __device__ __forceinline__ void mi_pgroup(const uint32_t *sBinW, uint32_t *sHist
         }
         if (u >= 1) {
             uint64_t d[KD];
+            if constexpr (DHEAD) {
 #pragma unroll
-            for (int kk = 0; kk < KD; ++kk) d[kk] = dlook(dtab, old[(u - 1) & 1][kk]);
+                for (int kk = 0; kk < KD; ++kk) {
+                    const uint32_t o = old[(u - 1) & 1][kk];
+                    mx = max(mx, o);                // a count past the head: the caller repeats the stage (see there)
+                    d[kk] = dlook(sDh, o);          // ds_read_b64
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KD; ++kk) d[kk] = dlook(dtab, old[(u - 1) & 1][kk]);
+            }
             uint64_t a = last_ok ? d[KD - 1] : 0ull;
 #pragma unroll
             for (int kk = 0; kk < KD - 1; ++kk) a += d[kk];
@@ -541,14 +557,15 @@ __device__ __forceinline__ void mi_pgroup(const uint32_t *sBinW, uint32_t *sHist
 // The partner-major MI stage.  Anchor a: 0..1 = r0, r1; 2..3 = p0, p1; 4..6 = c0..c2.  Pair index = position in
 // ComputeCFWeights' call order (rpf.cpp:416-442).  Marginal sums sHXf: every partner's from its own group (f0..f11,
 // c0..c2 are all partners), r0 r1 p0 p1 from the row sums of the c0 group's four histograms.
-template <int KD, int KW, int ZN, int PACK5>
-__device__ __forceinline__ void mi_stage_pm(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, const uint64_t *ttab,
+template <int KD, int KW, int ZN, int PACK5, bool DHEAD>
+__device__ __forceinline__ uint32_t mi_stage_pm(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, const uint64_t *sDh, const uint64_t *ttab,
                                             uint64_t *sHXf, uint64_t *sPairF, int lane, int n, int B) {
     constexpr int NA = 7;
     const int ncell2 = B * B;
     const bool last_ok = (lane + kWave * (KD - 1)) < n;                 // does this lane's last sample slot exist?
     const uint32_t hole4 = (uint32_t)min(lane, ncell2 - 1) << 2;        // harmless, spread-out targets of the +0 atomics
     zero_cells<ZN>(sHist, ncell2, lane);
+    uint32_t mx = 0u; // largest count any look-up of this lane saw (DHEAD)
     uint32_t akey4[NA][KD];
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
@@ -564,7 +581,7 @@ __device__ __forceinline__ void mi_stage_pm(const uint32_t *sBinW, uint32_t *sHi
 #pragma unroll 1
     for (int i = 0; i < kNFeat; ++i) { // feature partners: 7 histograms each
         uint64_t acc[8], macc = 0ull, racc[4];
-        mi_pgroup<KD, KW, ZN, 7, NA, PACK5, 1>(sBinW, sHist, dtab, ttab, lane, B, kColF + i, akey4, last_ok, hole4, ncell2, acc, macc, racc);
+        mi_pgroup<KD, KW, ZN, 7, NA, PACK5, 1, DHEAD>(sBinW, sHist, dtab, sDh, ttab, lane, B, kColF + i, akey4, last_ok, hole4, ncell2, acc, macc, racc, mx);
         acc[7] = macc; // the free eighth slot carries the partner's marginal
         const uint64_t tot = xl::reduce8<xl::OpSum>(acc, lane);
         if ((lane & 7) == 0) {
@@ -576,8 +593,8 @@ __device__ __forceinline__ void mi_stage_pm(const uint32_t *sBinW, uint32_t *sHi
 #pragma unroll 1
     for (int c = 0; c < 3; ++c) { // colour partners: 4 histograms each (anchors r0 r1 p0 p1)
         uint64_t acc[8], macc = 0ull, racc[4] = {0ull, 0ull, 0ull, 0ull};
-        if (c == 0) mi_pgroup<KD, KW, ZN, 4, NA, PACK5, 3>(sBinW, sHist, dtab, ttab, lane, B, kColC, akey4, last_ok, hole4, ncell2, acc, macc, racc);
-        else mi_pgroup<KD, KW, ZN, 4, NA, PACK5, 1>(sBinW, sHist, dtab, ttab, lane, B, kColC + c, akey4, last_ok, hole4, ncell2, acc, macc, racc);
+        if (c == 0) mi_pgroup<KD, KW, ZN, 4, NA, PACK5, 3, DHEAD>(sBinW, sHist, dtab, sDh, ttab, lane, B, kColC, akey4, last_ok, hole4, ncell2, acc, macc, racc, mx);
+        else mi_pgroup<KD, KW, ZN, 4, NA, PACK5, 1, DHEAD>(sBinW, sHist, dtab, sDh, ttab, lane, B, kColC + c, akey4, last_ok, hole4, ncell2, acc, macc, racc, mx);
         acc[7] = macc;
         if (c == 0) { acc[4] = racc[0]; acc[5] = racc[1]; acc[6] = racc[2]; }
         const uint64_t tot = xl::reduce8<xl::OpSum>(acc, lane);
@@ -589,6 +606,19 @@ __device__ __forceinline__ void mi_stage_pm(const uint32_t *sBinW, uint32_t *sHi
             else if (c == 0) sHXf[sl == 4 ? kColR : (sl == 5 ? kColR + 1 : kColP)] = tot;
         }
         if (c == 0 && lane == 0) sHXf[kColP + 1] = r3;
+    }
+    return mx;
+}
+
+template <int KD, int KW, int ZN, int PACK5, bool DHEAD>
+__device__ __forceinline__ void mi_pm(const uint32_t *sBinW, uint32_t *sHist, const uint64_t *dtab, const uint64_t *sDh,
+                                      const uint64_t *ttab, uint64_t *sHXf, uint64_t *sPairF, int lane, int n, int B) {
+    const uint32_t mx = mi_stage_pm<KD, KW, ZN, PACK5, DHEAD>(sBinW, sHist, dtab, sDh, ttab, sHXf, sPairF, lane, n, B);
+    if constexpr (DHEAD) {
+        if (__any(mx >= (uint32_t)kDHead)) { // some cell count ran past the LDS head of the table: once more, full table
+            wsync();
+            mi_stage_pm<KD, KW, ZN, PACK5, false>(sBinW, sHist, dtab, sDh, ttab, sHXf, sPairF, lane, n, B);
+        }
     }
 }
 
@@ -941,8 +971,11 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
     const uint64_t pix = (uint64_t)y * W + x;
 
 
-    if (T_IN_LDS)
+    if (T_IN_LDS) {
         for (int k = tid; k < p.nmax; k += kThreads) sD[k] = p.dfix[k];
+    } else if (K <= 8) {
+        for (int k = tid; k < min(p.nmax, kDHead); k += kThreads) sD[k] = p.dfix[k]; // the head of the table (mi_pgroup)
+    }
 
     // ---------------- stage 1b: neighbourhood membership (rpf.cpp:556-586) ----------------------
     const int x0 = max(x - b, 0), x1 = min(x + b, W - 1);
@@ -1431,10 +1464,10 @@ __global__ __launch_bounds__(64 * NW, (NW > 1 ? (K <= 25 ? 2 : 1) : (K <= 8 ? 3 
     if constexpr (K >= KD_) {                                                                                \
         if constexpr (KD_ == 1) mi_stage_tiny<KW, PACK5>(sBinW, sHist, p.tfix, sHXf, sPairF, lane, n, B); /* B*B <= 64 */ \
         else if constexpr (KD_ == 2) mi_stage_deep<KD_, KW, 1, PACK5>(sBinW, sHist, dtab, sHXf, sPairF, lane, n, B); /* B*B <= 121 */ \
-        else if (B * B <= 256) mi_stage_pm<KD_, KW, 1, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B); \
-        else if (B * B <= 320) mi_stage_pm<KD_, KW, 3, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B); \
-        else if (B * B <= 384) mi_stage_pm<KD_, KW, 4, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B); \
-        else mi_stage_pm<KD_, KW, 2, PACK5>(sBinW, sHist, dtab, p.tfix, sHXf, sPairF, lane, n, B);               \
+        else if (B * B <= 256) mi_pm<KD_, KW, 1, PACK5, !T_IN_LDS>(sBinW, sHist, dtab, sD, p.tfix, sHXf, sPairF, lane, n, B); \
+        else if (B * B <= 320) mi_pm<KD_, KW, 3, PACK5, !T_IN_LDS>(sBinW, sHist, dtab, sD, p.tfix, sHXf, sPairF, lane, n, B); \
+        else if (B * B <= 384) mi_pm<KD_, KW, 4, PACK5, !T_IN_LDS>(sBinW, sHist, dtab, sD, p.tfix, sHXf, sPairF, lane, n, B); \
+        else mi_pm<KD_, KW, 2, PACK5, !T_IN_LDS>(sBinW, sHist, dtab, sD, p.tfix, sHXf, sPairF, lane, n, B);               \
     }
             switch (kdyn) {
             case 1: RPF_MI_CASE(1) break;
@@ -2013,6 +2046,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun
     uint32_t o = 0;
     L.off_T = o;
     if (t_in_lds) o += align_up((uint32_t)nmax * 8u, 16);
+    else if (K <= 8) o += (uint32_t)kDHead * 8u; // the one-wave kernels keep the head of the D table in LDS
     L.off_stat = o; o += align_up(4 * kNDim * 8, 16);
     L.off_hx = o; o += align_up(kNDim * 8, 16);
     L.off_pair = o; o += align_up(kNPair * 8, 16);
