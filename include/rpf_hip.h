@@ -31,10 +31,14 @@
 extern "C" {
 #endif
 
-#define RPF_NDIM 19
+#define RPF_NDIM 19   /* the reference's sample vector (sd.h:21-49); other layouts: rpf_desc.n_random / n_feat */
 #define RPF_NFEAT 12
 #define RPF_NPAIR 96
 #define RPF_MAX_BOXES 8
+/* general layout: columns [0,2) pFilm | [2,5) colour | [5,5+nR) random parameters | [5+nR,5+nR+nF) features */
+#define RPF_NDIM_OF(nR, nF) (5 + (nR) + (nF))
+#define RPF_NPAIR_OF(nR, nF) ((nF) * ((nR) + 2) + 3 * ((nR) + 2 + (nF))) /* MI pairs, rpf.cpp:416-442 generalised */
+enum { RPF_PLANES_F32 = 0, RPF_PLANES_F16 = 1 };
 
 typedef struct rpf_ctx rpf_ctx;
 
@@ -87,6 +91,15 @@ typedef struct rpf_desc {
     int32_t flags;
     double eps;                        /* RPF_DEGEN_EPS epsilon (1e-10)                             */
     double sigma_seed;                 /* rpf.cpp:533: 0.002                                        */
+    /* Sample-vector layout.  All three 0 = the reference's: 2 random parameters (pLens), 12 features, fp32 planes.
+     * Kernels also exist for n_random = 4, n_feat = 18 with RPF_PLANES_F16 (27 dims, fp16 feature storage: BASELINE
+     * configs[4]); anything else returns RPF_E_UNSUPPORTED.  With fp16 planes every `planes` pointer of this header
+     * addresses 16-bit IEEE halves instead of floats; colours are still carried as fp64, outputs stay fp32.
+     * Per-pixel debug planes are then sized by RPF_NDIM_OF / RPF_NPAIR_OF / n_feat. */
+    int32_t n_random;
+    int32_t n_feat;
+    int32_t plane_dtype;               /* RPF_PLANES_F32 / RPF_PLANES_F16                           */
+    int32_t reserved;
 } rpf_desc;
 
 /* per-pixel stage outputs for parity tests; every pointer may be NULL; indexed [y*W+x] */
@@ -133,7 +146,7 @@ const char *rpf_last_error(const rpf_ctx *ctx);
  *   sample_rgb_out  host, 3 fp32 planes [3][H][W][S] of filtered sample colours, or NULL
  *   pixel_rgb_out   host, [H][W][3] fp32 mean over s of colour*rayWeight (rows outside the slab: unfiltered), or NULL
  */
-int32_t rpf_filter(rpf_ctx *ctx, const rpf_desc *desc, const float *planes, const float *ray_weight,
+int32_t rpf_filter(rpf_ctx *ctx, const rpf_desc *desc, const void *planes, const float *ray_weight,
                    float *sample_rgb_out, float *pixel_rgb_out);
 
 /* rpf_filter() with the sample colours carried as doubles across the boundary, as the reference carries them in
@@ -143,7 +156,7 @@ int32_t rpf_filter(rpf_ctx *ctx, const rpf_desc *desc, const float *planes, cons
  *   colour64_in   host, 3 fp64 planes [3][H][W][S], or NULL (= planes 2..4 of `planes`)
  *   colour64_out  host, 3 fp64 planes of filtered colours, or NULL
  * With either pointer set the call runs upload, passes, download one after the other (no row-band overlap). */
-int32_t rpf_filter_ex(rpf_ctx *ctx, const rpf_desc *desc, const float *planes, const double *colour64_in,
+int32_t rpf_filter_ex(rpf_ctx *ctx, const rpf_desc *desc, const void *planes, const double *colour64_in,
                       const float *ray_weight, float *sample_rgb_out, float *pixel_rgb_out, double *colour64_out);
 
 /* Per-context tuning / diagnostic overrides (nothing in the library reads the environment).  Names:
@@ -166,11 +179,11 @@ int32_t rpf_host_free(rpf_ctx *ctx, void *ptr); /* ctx may be NULL */
  * d_planes are ignored.  Runs on `stream`: the hipStream_t on which the caller produced the buffers (NULL = the
  * legacy default stream, e.g. PyTorch's default stream), so the pass is ordered after that work without an explicit
  * synchronisation.  Returns after the stream has drained (the status and the counters are read back). */
-int32_t rpf_filter_device(rpf_ctx *ctx, const rpf_desc *desc, const float *d_planes, double *d_colour,
+int32_t rpf_filter_device(rpf_ctx *ctx, const rpf_desc *desc, const void *d_planes, double *d_colour,
                           void *stream);
 
 /* fp32 colour planes (planes 2..4 of d_planes) -> fp64 colour planes; and back, plus the pixel mean */
-int32_t rpf_colour_from_planes_device(rpf_ctx *ctx, const rpf_desc *desc, const float *d_planes,
+int32_t rpf_colour_from_planes_device(rpf_ctx *ctx, const rpf_desc *desc, const void *d_planes,
                                       double *d_colour, void *stream);
 int32_t rpf_reduce_device(rpf_ctx *ctx, const rpf_desc *desc, const double *d_colour, const float *d_ray_weight,
                           float *d_sample_rgb_out, float *d_pixel_rgb_out, void *stream);
@@ -178,11 +191,11 @@ int32_t rpf_reduce_device(rpf_ctx *ctx, const rpf_desc *desc, const double *d_co
 /* ---- stage-level entry points (host buffers; used by the parity tests) ---------------------------- */
 
 /* stage 1a, FillMeanAndStddev (rpf.cpp:302-353): mean/std [H*W*12] fp64, pixel-major */
-int32_t rpf_stage_pixel_stats(rpf_ctx *ctx, const rpf_desc *desc, const float *planes, double *mean, double *stddev);
+int32_t rpf_stage_pixel_stats(rpf_ctx *ctx, const rpf_desc *desc, const void *planes, double *mean, double *stddev);
 
 /* one pass with one box size; colour_in (3 fp64 planes) may be NULL (= planes 2..4); colour_out 3 fp64
  * planes; dbg host pointers, any may be NULL */
-int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *desc, int32_t box, const float *planes,
+int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *desc, int32_t box, const void *planes,
                               const double *colour_in, double *colour_out, const rpf_debug *dbg);
 
 /* counters of the most recent rpf_filter / rpf_filter_device / rpf_filter_pass_debug call */
@@ -191,12 +204,33 @@ int32_t rpf_query_counters(rpf_ctx *ctx, rpf_counters *out);
 /* visualizeSF (rpf.cpp:37-101, visualization/vis.cpp:34-51): the reference's six debug images, without the EXR
  * writer: per-pixel mean over the S samples of n0, n1, p0, p1, (pFilm.x, pFilm.y, 0), (pLens.x, pLens.y, 0), each
  * channel divided by its maximum over the image.  images_out: host, fp64 [6][H][W][3] in that order. */
-int32_t rpf_feature_images(rpf_ctx *ctx, const rpf_desc *desc, const float *planes, double *images_out);
+int32_t rpf_feature_images(rpf_ctx *ctx, const rpf_desc *desc, const void *planes, double *images_out);
 
 /* device self-test: the kernels divide by wave-uniform divisors with a hoisted reciprocal (3 instructions per
  * quotient); this compares n pseudo-random quotients bit-for-bit with the compiler's IEEE fp64 division.
  * mode 0: operand magnitudes of the filter (2^-40..2^40); mode 1: 2^-600..2^600 (exercises the fallback). */
 int32_t rpf_selftest_udiv(rpf_ctx *ctx, uint64_t n, uint64_t seed, int32_t mode, uint64_t *mismatches);
+
+/* ---- one caller, every GPU of the node -------------------------------------------------------------------------
+ * The reference's caller is a single process (RPFIntegrator::Render, rpf.cpp:737-805, reached from api.cpp:1620).  A
+ * rpf_multi owns one context per entry of `devices` (NULL / 0 = every visible device; an ordinal may repeat: two slabs
+ * on one GPU rehearse the path on a one-GPU box) and rpf_multi_filter() is rpf_filter() for the whole image: it cuts
+ * the image into contiguous row slabs (rows [g*H/G, (g+1)*H/G) on entry g), uploads each slab with the halo rows of its
+ * neighbours ((box-1)/2 rows, rpf.cpp:561-571), runs every pass on all slabs concurrently, and refreshes the colour
+ * halo between passes with peer-to-peer copies of the neighbour's owned boundary rows (features never change, so their
+ * halo travels with the upload).  Results are bit-identical to rpf_filter() on one device.  desc->row_begin / row_end
+ * must name the whole image; a slab must own at least (box-1)/2 rows.  One caller thread per rpf_multi. */
+typedef struct rpf_multi rpf_multi;
+int32_t rpf_multi_create(rpf_multi **out, const int32_t *devices, int32_t n_devices);
+void rpf_multi_destroy(rpf_multi *m);
+const char *rpf_multi_last_error(const rpf_multi *m);
+int32_t rpf_multi_device_count(const rpf_multi *m);
+int32_t rpf_multi_set_option(rpf_multi *m, const char *name, int64_t value);
+int32_t rpf_multi_filter(rpf_multi *m, const rpf_desc *desc, const void *planes, const float *ray_weight,
+                         float *sample_rgb_out, float *pixel_rgb_out);
+/* merged over the slabs: sums, maxima, the lowest offending image pixel; filter_kernel_ms = sum over passes of the
+ * slowest slab's kernel time */
+int32_t rpf_multi_query_counters(rpf_multi *m, rpf_counters *out);
 
 /* LDS bytes per workgroup the fused kernel needs for (S, box); > device limit => RPF_E_UNSUPPORTED */
 int64_t rpf_lds_bytes_required(int32_t S, int32_t box);

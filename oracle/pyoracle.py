@@ -21,7 +21,13 @@ class Desc(C.Structure):
     _fields_ = [("W", C.c_int32), ("H", C.c_int32), ("S", C.c_int32), ("row_begin", C.c_int32),
                 ("row_end", C.c_int32), ("box", C.c_int32), ("beta_map", C.c_int32),
                 ("degenerate_policy", C.c_int32), ("eps", C.c_double), ("sigma_seed", C.c_double),
-                ("n_threads", C.c_int32), ("reserved", C.c_int32)]
+                ("n_threads", C.c_int32), ("reserved", C.c_int32), ("n_random", C.c_int32), ("n_feat", C.c_int32)]
+
+
+def dims(desc):
+    """(ndim, nfeat, npair) of a descriptor's sample layout (0 fields = the reference's 19 / 12 / 96)"""
+    nr, nf = desc.n_random or 2, desc.n_feat or 12
+    return 5 + nr + nf, nf, nf * (nr + 2) + 3 * (nr + 2 + nf)
 
 
 class Debug(C.Structure):
@@ -68,6 +74,7 @@ def lib():
                                              C.POINTER(Debug), C.POINTER(Result)]
         L.rpf_oracle_pixel_mean.argtypes = [C.POINTER(Desc), C.c_void_p, C.c_void_p, C.c_void_p]
         L.rpf_oracle_pair_table.argtypes = [C.c_void_p, C.c_void_p]
+        L.rpf_oracle_pair_table_ex.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.rpf_oracle_feature_images.argtypes = [C.POINTER(Desc), C.c_void_p, C.c_void_p]
         L.rpf_oracle_weighted_sqdist.argtypes = [C.c_void_p] * 5
         _lib = L
@@ -170,22 +177,24 @@ def ref_weighted_sqdist(zi, zj, alpha, beta):
                      R.ref_weighted_sqdist_12(_p(f_i), _p(f_j), _p(beta))])
 
 
-def pair_table():
-    a, b = np.empty(NPAIR, np.int32), np.empty(NPAIR, np.int32)
-    lib().rpf_oracle_pair_table(_p(a), _p(b))
+def pair_table(n_random=2, n_feat=12):
+    npair = n_feat * (n_random + 2) + 3 * (n_random + 2 + n_feat)
+    a, b = np.empty(npair, np.int32), np.empty(npair, np.int32)
+    lib().rpf_oracle_pair_table_ex(n_random, n_feat, _p(a), _p(b))
     return a, b
 
 
 def make_desc(W, H, S, box=7, row_begin=0, row_end=None, beta_map=BETA_REF_GCC11_O3, policy=DEGEN_REF_ABORT,
-              eps=1e-10, sigma_seed=0.002, n_threads=0):
+              eps=1e-10, sigma_seed=0.002, n_threads=0, n_random=0, n_feat=0):
     return Desc(W, H, S, row_begin, H if row_end is None else row_end, box, beta_map, policy, eps, sigma_seed,
-                n_threads, 0)
+                n_threads, 0, n_random, n_feat)
 
 
 def pixel_stats(planes, desc):
     planes = np.ascontiguousarray(planes, np.float32)
-    m = np.empty((desc.H, desc.W, NFEAT))
-    s = np.empty((desc.H, desc.W, NFEAT))
+    nf = dims(desc)[1]
+    m = np.empty((desc.H, desc.W, nf))
+    s = np.empty((desc.H, desc.W, nf))
     lib().rpf_oracle_pixel_stats(C.byref(desc), _p(planes), _p(m), _p(s))
     return m, s
 
@@ -199,8 +208,9 @@ def cf_weights(z, beta_map=BETA_REF_GCC11_O3, policy=DEGEN_REF_ABORT, eps=1e-10)
 
 def filter_pass(planes, desc, colour_in=None, debug=True):
     """planes: float32 [19,H,W,S]. Returns dict(colour=[3,H,W,S] f64, result fields, debug planes)."""
-    planes = np.ascontiguousarray(planes, np.float32)
-    assert planes.shape == (NDIM, desc.H, desc.W, desc.S), planes.shape
+    planes = np.ascontiguousarray(planes, np.float32)   # (an fp16-stored buffer: its exact fp32 image)
+    nd, nf, npair = dims(desc)
+    assert planes.shape == (nd, desc.H, desc.W, desc.S), planes.shape
     H, W, S = desc.H, desc.W, desc.S
     cin = None if colour_in is None else _f64(colour_in)
     out = np.empty((3, H, W, S))
@@ -208,9 +218,9 @@ def filter_pass(planes, desc, colour_in=None, debug=True):
     dbg = None
     d = {}
     if debug:
-        d = dict(nbhd_size=np.zeros((H, W), np.int32), mean=np.zeros((H, W, NDIM)), stddev=np.zeros((H, W, NDIM)),
-                 mi=np.zeros((H, W, NPAIR)), alpha=np.zeros((H, W, 3)), beta=np.zeros((H, W, 12)),
-                 wrc=np.zeros((H, W)), bin_hash=np.zeros((H, W, NDIM), np.uint32),
+        d = dict(nbhd_size=np.zeros((H, W), np.int32), mean=np.zeros((H, W, nd)), stddev=np.zeros((H, W, nd)),
+                 mi=np.zeros((H, W, npair)), alpha=np.zeros((H, W, 3)), beta=np.zeros((H, W, nf)),
+                 wrc=np.zeros((H, W)), bin_hash=np.zeros((H, W, nd), np.uint32),
                  member_hash=np.zeros((H, W), np.uint32))
         dbg = Debug(*[_p(d[k]) for k, _ in Debug._fields_])
     lib().rpf_oracle_filter_pass(C.byref(desc), _p(planes), _p(cin), _p(out),

@@ -15,23 +15,40 @@
 #include <omp.h>
 #endif
 
-enum { C_P0 = 0, C_C0 = 2, C_R0 = 5, C_F0 = 7 }; /* column groups, sd.h:62-94,149-214 */
+/* Column groups, sd.h:62-94,149-214: [0,2) pFilm | [2,5) colour | [5,5+nR) random parameters | [5+nR,5+nR+nF)
+ * features.  The reference has nR = 2 (pLens), nF = 12; the layout is a run-time parameter here so that the same
+ * statements also check BASELINE configs[4]'s 27-dim buffers (nR = 4, nF = 18).  With nR = 2, nF = 12 every loop below
+ * is the reference's. */
+enum { C_P0 = 0, C_C0 = 2, C_R0 = 5 };
+typedef struct { int nr, nf, nd, f0, npair; } dims_t;
+static dims_t dims_of(int nr, int nf) {
+    dims_t d;
+    d.nr = nr > 0 ? nr : 2;
+    d.nf = nf > 0 ? nf : 12;
+    d.nd = 5 + d.nr + d.nf;
+    d.f0 = C_R0 + d.nr;
+    d.npair = d.nf * (d.nr + 2) + 3 * (d.nr + 2 + d.nf);
+    return d;
+}
+static dims_t dims_desc(const rpf_oracle_desc *d) { return dims_of(d->n_random, d->n_feat); }
 
 /* ------------------------------------------------------------------------------------------------
  * pair order = call order of MutualInformation in ComputeCFWeights (rpf.cpp:416-442)
  * ---------------------------------------------------------------------------------------------- */
-void rpf_oracle_pair_table(int32_t a[RPF_O_NPAIR], int32_t b[RPF_O_NPAIR]) {
+void rpf_oracle_pair_table_ex(int32_t n_random, int32_t n_feat, int32_t *a, int32_t *b) {
+    const dims_t D = dims_of(n_random, n_feat);
     int p = 0;
-    for (int i = 0; i < 12; ++i) {
-        for (int l = 0; l < 2; ++l) { a[p] = C_F0 + i; b[p] = C_R0 + l; ++p; } /* rpf.cpp:418-422 */
-        for (int l = 0; l < 2; ++l) { a[p] = C_F0 + i; b[p] = C_P0 + l; ++p; } /* rpf.cpp:424-426 */
+    for (int i = 0; i < D.nf; ++i) {
+        for (int l = 0; l < D.nr; ++l) { a[p] = D.f0 + i; b[p] = C_R0 + l; ++p; } /* rpf.cpp:418-422 */
+        for (int l = 0; l < 2; ++l) { a[p] = D.f0 + i; b[p] = C_P0 + l; ++p; }    /* rpf.cpp:424-426 */
     }
     for (int c = 0; c < 3; ++c) {
-        for (int l = 0; l < 2; ++l) { a[p] = C_C0 + c; b[p] = C_R0 + l; ++p; } /* rpf.cpp:431-433 */
-        for (int l = 0; l < 2; ++l) { a[p] = C_C0 + c; b[p] = C_P0 + l; ++p; } /* rpf.cpp:435-437 */
-        for (int j = 0; j < 12; ++j) { a[p] = C_C0 + c; b[p] = C_F0 + j; ++p; } /* rpf.cpp:439-441 */
+        for (int l = 0; l < D.nr; ++l) { a[p] = C_C0 + c; b[p] = C_R0 + l; ++p; } /* rpf.cpp:431-433 */
+        for (int l = 0; l < 2; ++l) { a[p] = C_C0 + c; b[p] = C_P0 + l; ++p; }    /* rpf.cpp:435-437 */
+        for (int j = 0; j < D.nf; ++j) { a[p] = C_C0 + c; b[p] = D.f0 + j; ++p; } /* rpf.cpp:439-441 */
     }
 }
+void rpf_oracle_pair_table(int32_t a[RPF_O_NPAIR], int32_t b[RPF_O_NPAIR]) { rpf_oracle_pair_table_ex(2, 12, a, b); }
 
 /* x86-64 cvttsd2si semantics of static_cast<int>(double) for NaN / out-of-range (mi.cpp:14,29,35) */
 static int to_int_x86(double v) {
@@ -154,75 +171,79 @@ static void clamp_var_eps(double *sd, int n, int policy) {
 /* rpf.cpp:338-347 for one pixel */
 static void pixel_feature_stats(const rpf_oracle_desc *d, const float *planes, int y, int x, double *m12,
                                 double *sd12) {
+    const dims_t D = dims_desc(d);
     const size_t ps = plane_stride(d);
-    double *r = (double *)malloc(sizeof(double) * (size_t)d->S * RPF_O_NFEAT);
+    double *r = (double *)malloc(sizeof(double) * (size_t)d->S * D.nf);
     for (int s = 0; s < d->S; ++s)
-        for (int k = 0; k < RPF_O_NFEAT; ++k) r[s * RPF_O_NFEAT + k] = planes[(C_F0 + k) * ps + sample_off(d, y, x, s)];
-    rpf_oracle_mean_std(r, d->S, RPF_O_NFEAT, m12, sd12);
-    clamp_var_eps(sd12, RPF_O_NFEAT, d->degenerate_policy);
+        for (int k = 0; k < D.nf; ++k) r[s * D.nf + k] = planes[(D.f0 + k) * ps + sample_off(d, y, x, s)];
+    rpf_oracle_mean_std(r, d->S, D.nf, m12, sd12);
+    clamp_var_eps(sd12, D.nf, d->degenerate_policy);
     free(r);
 }
 
 void rpf_oracle_pixel_stats(const rpf_oracle_desc *d, const float *planes, double *mean, double *stddev) {
+    const int nf = dims_desc(d).nf;
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < d->H; ++y)
         for (int x = 0; x < d->W; ++x) {
             size_t p = (size_t)y * d->W + x;
-            pixel_feature_stats(d, planes, y, x, mean + p * RPF_O_NFEAT, stddev + p * RPF_O_NFEAT);
+            pixel_feature_stats(d, planes, y, x, mean + p * nf, stddev + p * nf);
         }
 }
 
 /* rpf.cpp:356-488 on a normalised neighbourhood (z: n x 19, row major) */
 typedef struct {
-    double *col[RPF_O_NDIM]; /* 19 column vectors of length n (rpf.cpp:381-412) */
+    double *col[RPF_O_MAXDIM]; /* the column vectors of length n (rpf.cpp:381-412) */
     int *hx, *hy, *joint;
     const int64_t *tfix;     /* EPS residue contract table (mi_scratch), NULL under REF_ABORT */
 } cf_scratch;
 
-static void cf_weights_core(const double *z, int n, int beta_map, int policy, double eps, cf_scratch *sc,
-                            double alpha[3], double beta[12], double *wrc, double *mi96) {
-    for (int c = 0; c < RPF_O_NDIM; ++c)
-        for (int i = 0; i < n; ++i) sc->col[c][i] = z[(size_t)i * RPF_O_NDIM + c];
+static void cf_weights_core(const double *z, int n, dims_t D, int beta_map, int policy, double eps, cf_scratch *sc,
+                            double alpha[3], double *beta, double *wrc, double *mi_out) {
+    const int nd = D.nd, nf = D.nf, nr = D.nr, F0 = D.f0;
+    for (int c = 0; c < nd; ++c)
+        for (int i = 0; i < n; ++i) sc->col[c][i] = z[(size_t)i * nd + c];
 
-    double D_r_fk[12], D_p_fk[12], D_r_ck[3], D_p_ck[3], D_f_ck[3]; /* rpf.cpp:363-377 */
-    double D_cf_k[12];                                              /* sum_c MI(c_c,f_k): PAPER numerator */
-    for (int i = 0; i < 12; ++i) { D_r_fk[i] = 0; D_p_fk[i] = 0; D_cf_k[i] = 0; }
+    double D_r_fk[RPF_O_MAXDIM], D_p_fk[RPF_O_MAXDIM], D_r_ck[3], D_p_ck[3], D_f_ck[3]; /* rpf.cpp:363-377 */
+    double D_cf_k[RPF_O_MAXDIM];                                    /* sum_c MI(c_c,f_k): PAPER numerator */
+    for (int i = 0; i < nf; ++i) { D_r_fk[i] = 0; D_p_fk[i] = 0; D_cf_k[i] = 0; }
     for (int i = 0; i < 3; ++i) { D_r_ck[i] = 0; D_p_ck[i] = 0; D_f_ck[i] = 0; }
+    const int64_t *tf = policy == RPF_O_DEGEN_EPS ? sc->tfix : NULL;
 
     int p = 0;
     double v;
-    for (int i = 0; i < 12; ++i) { /* rpf.cpp:416-427 */
-        for (int j = 0; j < 2; ++j) {
-            v = mi_scratch(sc->col[C_F0 + i], sc->col[C_R0 + j], n, sc->hx, sc->hy, sc->joint, policy == RPF_O_DEGEN_EPS ? sc->tfix : NULL);
+    for (int i = 0; i < nf; ++i) { /* rpf.cpp:416-427 */
+        for (int j = 0; j < nr; ++j) {
+            v = mi_scratch(sc->col[F0 + i], sc->col[C_R0 + j], n, sc->hx, sc->hy, sc->joint, tf);
             D_r_fk[i] += v;
-            if (mi96) mi96[p] = v;
+            if (mi_out) mi_out[p] = v;
             ++p;
         }
         for (int j = 0; j < 2; ++j) {
-            v = mi_scratch(sc->col[C_F0 + i], sc->col[C_P0 + j], n, sc->hx, sc->hy, sc->joint, policy == RPF_O_DEGEN_EPS ? sc->tfix : NULL);
+            v = mi_scratch(sc->col[F0 + i], sc->col[C_P0 + j], n, sc->hx, sc->hy, sc->joint, tf);
             D_p_fk[i] += v;
-            if (mi96) mi96[p] = v;
+            if (mi_out) mi_out[p] = v;
             ++p;
         }
     }
     for (int i = 0; i < 3; ++i) { /* rpf.cpp:429-442 */
-        for (int j = 0; j < 2; ++j) {
-            v = mi_scratch(sc->col[C_C0 + i], sc->col[C_R0 + j], n, sc->hx, sc->hy, sc->joint, policy == RPF_O_DEGEN_EPS ? sc->tfix : NULL);
+        for (int j = 0; j < nr; ++j) {
+            v = mi_scratch(sc->col[C_C0 + i], sc->col[C_R0 + j], n, sc->hx, sc->hy, sc->joint, tf);
             D_r_ck[i] += v;
-            if (mi96) mi96[p] = v;
+            if (mi_out) mi_out[p] = v;
             ++p;
         }
         for (int j = 0; j < 2; ++j) {
-            v = mi_scratch(sc->col[C_C0 + i], sc->col[C_P0 + j], n, sc->hx, sc->hy, sc->joint, policy == RPF_O_DEGEN_EPS ? sc->tfix : NULL);
+            v = mi_scratch(sc->col[C_C0 + i], sc->col[C_P0 + j], n, sc->hx, sc->hy, sc->joint, tf);
             D_p_ck[i] += v;
-            if (mi96) mi96[p] = v;
+            if (mi_out) mi_out[p] = v;
             ++p;
         }
-        for (int j = 0; j < 12; ++j) {
-            v = mi_scratch(sc->col[C_C0 + i], sc->col[C_F0 + j], n, sc->hx, sc->hy, sc->joint, policy == RPF_O_DEGEN_EPS ? sc->tfix : NULL);
+        for (int j = 0; j < nf; ++j) {
+            v = mi_scratch(sc->col[C_C0 + i], sc->col[F0 + j], n, sc->hx, sc->hy, sc->joint, tf);
             D_f_ck[i] += v;
             D_cf_k[j] += v;
-            if (mi96) mi96[p] = v;
+            if (mi_out) mi_out[p] = v;
             ++p;
         }
     }
@@ -231,22 +252,23 @@ static void cf_weights_core(const double *z, int n, int beta_map, int policy, do
     for (int i = 0; i < 3; ++i) { D_f_c += D_f_ck[i]; D_r_c += D_r_ck[i]; D_p_c += D_p_ck[i]; }
 
     const double e = (policy == RPF_O_DEGEN_EPS) ? eps : 0.0;
-    double num[12]; /* what rpf.cpp:464 reads as D_f_ck[i], i<12, on a 3-array */
-    for (int k = 0; k < 12; ++k) {
+    double num[RPF_O_MAXDIM]; /* what rpf.cpp:464 reads as D_f_ck[i], i < nF, on a 3-array; for nF != 12
+                               * the presets keep the same stack rule (k < 3: D_f_ck, a gap of zeros, then D_r_fk) */
+    for (int k = 0; k < nf; ++k) {
         switch (beta_map) {
         case RPF_O_BETA_REF_GCC11_O2: num[k] = k < 3 ? D_f_ck[k] : (k < 8 ? 0.0 : D_r_fk[k - 8]); break;
         case RPF_O_BETA_PAPER: num[k] = D_cf_k[k]; break;
         default: num[k] = k < 3 ? D_f_ck[k] : (k < 4 ? 0.0 : D_r_fk[k - 4]); break;
         }
     }
-    double W_c_fk[12], W_r_fk[12], W_r_ck[3];
-    for (int i = 0; i < 12; ++i) { /* rpf.cpp:463-466 */
+    double W_c_fk[RPF_O_MAXDIM], W_r_fk[RPF_O_MAXDIM], W_r_ck[3];
+    for (int i = 0; i < nf; ++i) { /* rpf.cpp:463-466 */
         W_c_fk[i] = num[i] / (D_f_c + D_r_c + D_p_c + e);
         W_r_fk[i] = D_r_fk[i] / (D_r_fk[i] + D_p_fk[i] + e);
     }
     for (int i = 0; i < 3; ++i) W_r_ck[i] = D_r_ck[i] / (D_r_ck[i] + D_p_ck[i] + e); /* rpf.cpp:469-471 */
     for (int i = 0; i < 3; ++i) alpha[i] = 1 - W_r_ck[i];                            /* rpf.cpp:474-476 */
-    for (int i = 0; i < 12; ++i) beta[i] = (1 - W_r_fk[i]) * W_c_fk[i];              /* rpf.cpp:478-480 */
+    for (int i = 0; i < nf; ++i) beta[i] = (1 - W_r_fk[i]) * W_c_fk[i];              /* rpf.cpp:478-480 */
     double w = 0;                                                                    /* rpf.cpp:483-487 */
     for (int i = 0; i < 3; ++i) w += W_r_ck[i];
     w /= 3;
@@ -255,14 +277,14 @@ static void cf_weights_core(const double *z, int n, int beta_map, int policy, do
 
 static void cf_scratch_alloc(cf_scratch *sc, int nmax) {
     int bins = (int)sqrt((double)nmax) + 1;
-    for (int c = 0; c < RPF_O_NDIM; ++c) sc->col[c] = (double *)malloc(sizeof(double) * (size_t)nmax);
+    for (int c = 0; c < RPF_O_MAXDIM; ++c) sc->col[c] = (double *)malloc(sizeof(double) * (size_t)nmax);
     sc->hx = (int *)malloc(sizeof(int) * (size_t)(2 * bins + bins * bins));
     sc->hy = sc->hx + bins;
     sc->joint = sc->hy + bins;
     sc->tfix = NULL;
 }
 static void cf_scratch_free(cf_scratch *sc) {
-    for (int c = 0; c < RPF_O_NDIM; ++c) free(sc->col[c]);
+    for (int c = 0; c < RPF_O_MAXDIM; ++c) free(sc->col[c]);
     free(sc->hx);
 }
 
@@ -272,7 +294,7 @@ void rpf_oracle_cf_weights(const double *z, int32_t n, int32_t beta_map, int32_t
     cf_scratch_alloc(&sc, n);
     int64_t *tf = policy == RPF_O_DEGEN_EPS ? tfix_table(n) : NULL;
     sc.tfix = tf;
-    cf_weights_core(z, n, beta_map, policy, eps, &sc, alpha, beta, wrc, mi96);
+    cf_weights_core(z, n, dims_of(2, 12), beta_map, policy, eps, &sc, alpha, beta, wrc, mi96);
     cf_scratch_free(&sc);
     free(tf);
 }
@@ -280,17 +302,17 @@ void rpf_oracle_cf_weights(const double *z, int32_t n, int32_t beta_map, int32_t
 /* rpf.cpp:646-660: the three weighted squared distances of a pair of NORMALISED samples (19 columns each):
  * sumArray(squareArray(subtractArrays(P_i, P_j))), sumArray(multiplyArrays(squareArray(subtractArrays(C_i, C_j)), Alpha)),
  * sumArray(multiplyArrays(squareArray(subtractArrays(F_i, F_j)), Beta)) -- ops.h:17-97, sequential sums from 0 */
-static void weighted_sqdist(const double *si, const double *sj, const double *alpha, const double *beta, double *sp_,
-                            double *sc_, double *sf_) {
+static void weighted_sqdist(const double *si, const double *sj, dims_t D, const double *alpha, const double *beta,
+                            double *sp_, double *sc_, double *sf_) {
     double sp = 0, scol = 0, sf = 0;
     for (int k = 0; k < 2; ++k) { double t = si[C_P0 + k] - sj[C_P0 + k]; sp += t * t; }
     for (int k = 0; k < 3; ++k) { double t = si[C_C0 + k] - sj[C_C0 + k]; scol += (t * t) * alpha[k]; }
-    for (int k = 0; k < 12; ++k) { double t = si[C_F0 + k] - sj[C_F0 + k]; sf += (t * t) * beta[k]; }
+    for (int k = 0; k < D.nf; ++k) { double t = si[D.f0 + k] - sj[D.f0 + k]; sf += (t * t) * beta[k]; }
     *sp_ = sp; *sc_ = scol; *sf_ = sf;
 }
 void rpf_oracle_weighted_sqdist(const double *zi, const double *zj, const double alpha[3], const double beta[12],
                                 double out3[3]) {
-    weighted_sqdist(zi, zj, alpha, beta, &out3[0], &out3[1], &out3[2]);
+    weighted_sqdist(zi, zj, dims_of(2, 12), alpha, beta, &out3[0], &out3[1], &out3[2]);
 }
 
 static uint32_t fnv1a_u32(uint32_t h, uint32_t v) {
@@ -305,6 +327,8 @@ static uint32_t fnv1a_u16(uint32_t h, uint32_t v) {
 void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const double *colour_in,
                             double *colour_out, rpf_oracle_debug *dbg, rpf_oracle_result *res) {
     const int W = d->W, H = d->H, S = d->S, box = d->box;
+    const dims_t D = dims_desc(d);
+    const int ND = D.nd, NF = D.nf, F0 = D.f0;
     const int b = (box - 1) / 2; /* rpf.cpp:561 */
     const size_t ps = plane_stride(d);
     const int nmax = box * box * S;
@@ -317,8 +341,8 @@ void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const
             colour_out[c * ps + i] = colour_in ? colour_in[c * ps + i] : (double)planes[(C_C0 + c) * ps + i];
 
     /* stage 1a for every pixel of the buffer (rpf.cpp:519) */
-    double *pmean = (double *)malloc(sizeof(double) * (size_t)H * W * RPF_O_NFEAT);
-    double *pstd = (double *)malloc(sizeof(double) * (size_t)H * W * RPF_O_NFEAT);
+    double *pmean = (double *)malloc(sizeof(double) * (size_t)H * W * NF);
+    double *pstd = (double *)malloc(sizeof(double) * (size_t)H * W * NF);
     rpf_oracle_pixel_stats(d, planes, pmean, pstd);
 
     int32_t first_bad = INT_MAX, max_n = 0;
@@ -330,9 +354,9 @@ void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const
 #endif
 #pragma omp parallel
     {
-        double *nb = (double *)malloc(sizeof(double) * (size_t)nmax * RPF_O_NDIM);  /* raw neighbourhood */
-        double *z = (double *)malloc(sizeof(double) * (size_t)nmax * RPF_O_NDIM);   /* normalised */
-        double *zo = (double *)malloc(sizeof(double) * (size_t)S * RPF_O_NDIM);     /* normalised own */
+        double *nb = (double *)malloc(sizeof(double) * (size_t)nmax * ND);  /* raw neighbourhood */
+        double *z = (double *)malloc(sizeof(double) * (size_t)nmax * ND);   /* normalised */
+        double *zo = (double *)malloc(sizeof(double) * (size_t)S * ND);     /* normalised own */
         double *wm = (double *)malloc(sizeof(double) * (size_t)S * nmax);           /* weights_mat */
         uint32_t *code = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nmax);
         cf_scratch sc;
@@ -345,15 +369,15 @@ void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const
         for (int y = d->row_begin; y < d->row_end; ++y) {
             for (int x = 0; x < W; ++x) {
                 const size_t pix = (size_t)y * W + x;
-                const double *m12 = pmean + pix * RPF_O_NFEAT;
-                const double *s12 = pstd + pix * RPF_O_NFEAT;
+                const double *m12 = pmean + pix * NF;
+                const double *s12 = pstd + pix * NF;
                 int n = 0;
                 /* own samples first, unconditionally (rpf.cpp:558) */
                 for (int s = 0; s < S; ++s) {
                     size_t o = sample_off(d, y, x, s);
-                    for (int c = 0; c < RPF_O_NDIM; ++c) nb[(size_t)n * RPF_O_NDIM + c] = planes[c * ps + o];
+                    for (int c = 0; c < ND; ++c) nb[(size_t)n * ND + c] = planes[c * ps + o];
                     if (colour_in)
-                        for (int c = 0; c < 3; ++c) nb[(size_t)n * RPF_O_NDIM + C_C0 + c] = colour_in[c * ps + o];
+                        for (int c = 0; c < 3; ++c) nb[(size_t)n * ND + C_C0 + c] = colour_in[c * ps + o];
                     code[n] = (uint32_t)((b * box + b) * S + s);
                     ++n;
                 }
@@ -365,16 +389,16 @@ void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const
                         for (int s = 0; s < S; ++s) {
                             size_t o = sample_off(d, yn, xn, s);
                             int within = 1;
-                            for (int k = 0; k < RPF_O_NFEAT; ++k) { /* ops.h:99-107 : fail iff a >= b */
-                                double a = fabs((double)planes[(C_F0 + k) * ps + o] - m12[k]);
+                            for (int k = 0; k < NF; ++k) { /* ops.h:99-107 : fail iff a >= b */
+                                double a = fabs((double)planes[(F0 + k) * ps + o] - m12[k]);
                                 double lim = s12[k] * 3; /* rpf.cpp:579 */
                                 if (a >= lim) { within = 0; break; }
                             }
                             if (!within) continue;
-                            for (int c = 0; c < RPF_O_NDIM; ++c) nb[(size_t)n * RPF_O_NDIM + c] = planes[c * ps + o];
+                            for (int c = 0; c < ND; ++c) nb[(size_t)n * ND + c] = planes[c * ps + o];
                             if (colour_in)
                                 for (int c = 0; c < 3; ++c)
-                                    nb[(size_t)n * RPF_O_NDIM + C_C0 + c] = colour_in[c * ps + o];
+                                    nb[(size_t)n * ND + C_C0 + c] = colour_in[c * ps + o];
                             code[n] = (uint32_t)(((xn - x + b) * box + (yn - y + b)) * S + s);
                             ++n;
                         }
@@ -384,28 +408,28 @@ void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const
                 if (n > t_max) t_max = n;
 
                 /* stage 2: rpf.cpp:596-612 */
-                double M[RPF_O_NDIM], SD[RPF_O_NDIM];
-                rpf_oracle_mean_std(nb, n, RPF_O_NDIM, M, SD);
-                clamp_var_eps(SD, RPF_O_NDIM, d->degenerate_policy);
+                double M[RPF_O_MAXDIM], SD[RPF_O_MAXDIM];
+                rpf_oracle_mean_std(nb, n, ND, M, SD);
+                clamp_var_eps(SD, ND, d->degenerate_policy);
                 for (int i = 0; i < n; ++i)
-                    for (int c = 0; c < RPF_O_NDIM; ++c) { /* sd.h:229-232, ops.h:48 */
-                        double a = nb[(size_t)i * RPF_O_NDIM + c] - M[c];
-                        z[(size_t)i * RPF_O_NDIM + c] = SD[c] == 0 ? 0 : a / SD[c];
+                    for (int c = 0; c < ND; ++c) { /* sd.h:229-232, ops.h:48 */
+                        double a = nb[(size_t)i * ND + c] - M[c];
+                        z[(size_t)i * ND + c] = SD[c] == 0 ? 0 : a / SD[c];
                     }
                 for (int i = 0; i < S; ++i) /* own samples are entries 0..S-1 of the neighbourhood */
-                    for (int c = 0; c < RPF_O_NDIM; ++c) zo[i * RPF_O_NDIM + c] = z[(size_t)i * RPF_O_NDIM + c];
+                    for (int c = 0; c < ND; ++c) zo[i * ND + c] = z[(size_t)i * ND + c];
 
                 /* stage 3: rpf.cpp:615-623 */
-                double alpha[3], beta[12], wrc;
-                double *mi_out = (dbg && dbg->mi) ? dbg->mi + pix * RPF_O_NPAIR : NULL;
-                cf_weights_core(z, n, d->beta_map, d->degenerate_policy, d->eps, &sc, alpha, beta, &wrc, mi_out);
+                double alpha[3], beta[RPF_O_MAXDIM], wrc;
+                double *mi_out = (dbg && dbg->mi) ? dbg->mi + pix * D.npair : NULL;
+                cf_weights_core(z, n, D, d->beta_map, d->degenerate_policy, d->eps, &sc, alpha, beta, &wrc, mi_out);
 
                 if (dbg) {
                     if (dbg->nbhd_size) dbg->nbhd_size[pix] = n;
-                    if (dbg->mean) memcpy(dbg->mean + pix * RPF_O_NDIM, M, sizeof(M));
-                    if (dbg->stddev) memcpy(dbg->stddev + pix * RPF_O_NDIM, SD, sizeof(SD));
+                    if (dbg->mean) memcpy(dbg->mean + pix * ND, M, sizeof(double) * ND);
+                    if (dbg->stddev) memcpy(dbg->stddev + pix * ND, SD, sizeof(double) * ND);
                     if (dbg->alpha) memcpy(dbg->alpha + pix * 3, alpha, sizeof(alpha));
-                    if (dbg->beta) memcpy(dbg->beta + pix * 12, beta, sizeof(beta));
+                    if (dbg->beta) memcpy(dbg->beta + pix * NF, beta, sizeof(double) * NF);
                     if (dbg->wrc) dbg->wrc[pix] = wrc;
                     if (dbg->member_hash) {
                         uint32_t h = 2166136261u;
@@ -415,13 +439,13 @@ void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const
                     if (dbg->bin_hash) {
                         int bins = (int)sqrt((double)n);
                         if (bins < 1) bins = 1;
-                        for (int c = 0; c < RPF_O_NDIM; ++c) {
+                        for (int c = 0; c < ND; ++c) {
                             double lo, hi;
                             min_max(sc.col[c], n, &lo, &hi);
                             uint32_t h = 2166136261u;
                             for (int i = 0; i < n; ++i)
                                 h = fnv1a_u16(h, (uint32_t)(hi == lo ? 0 : bin_of(sc.col[c][i], lo, hi, bins)));
-                            dbg->bin_hash[pix * RPF_O_NDIM + c] = h;
+                            dbg->bin_hash[pix * ND + c] = h;
                         }
                     }
                 }
@@ -431,11 +455,11 @@ void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const
                 double sigma_f_squared = sigma_c_squared;
                 double sigma_p_squared = sigma_p * sigma_p;
                 for (int i = 0; i < S; ++i) {
-                    const double *si = zo + i * RPF_O_NDIM;
+                    const double *si = zo + i * ND;
                     for (int j = 0; j < n; ++j) {
-                        const double *sj = z + (size_t)j * RPF_O_NDIM;
+                        const double *sj = z + (size_t)j * ND;
                         double sp, scol, sf;
-                        weighted_sqdist(si, sj, alpha, beta, &sp, &scol, &sf);
+                        weighted_sqdist(si, sj, D, alpha, beta, &sp, &scol, &sf);
                         wm[(size_t)i * n + j] = exp(-sp / (2 * sigma_p_squared)) * exp(-scol / (2 * sigma_c_squared)) *
                                                 exp(-sf / (2 * sigma_f_squared)); /* rpf.cpp:667-670 */
                     }
@@ -448,12 +472,12 @@ void rpf_oracle_filter_pass(const rpf_oracle_desc *d, const float *planes, const
                         double sum_w = 0, sum_w_c = 0;
                         for (int j = 0; j < n; ++j) {
                             sum_w += wm[(size_t)i * n + j];
-                            sum_w_c += wm[(size_t)i * n + j] * nb[(size_t)j * RPF_O_NDIM + C_C0 + k];
+                            sum_w_c += wm[(size_t)i * n + j] * nb[(size_t)j * ND + C_C0 + k];
                         }
                         double prime = sum_w_c / sum_w;
                         if (isnan(prime)) { /* rpf.cpp:702-705: exit(1) in the reference */
                             bad = 1;
-                            if (d->degenerate_policy == RPF_O_DEGEN_EPS) prime = nb[(size_t)i * RPF_O_NDIM + C_C0 + k];
+                            if (d->degenerate_policy == RPF_O_DEGEN_EPS) prime = nb[(size_t)i * ND + C_C0 + k];
                         }
                         colour_out[k * ps + o] = prime;
                     }

@@ -37,9 +37,10 @@
 extern "C" {
 #endif
 
-#define RPF_O_NDIM 19
+#define RPF_O_NDIM 19   /* the reference's layout (n_random = 2, n_feat = 12); see rpf_oracle_desc for others */
 #define RPF_O_NFEAT 12
 #define RPF_O_NPAIR 96
+#define RPF_O_MAXDIM 40 /* upper bound on 5 + n_random + n_feat */
 
 /* beta numerator presets: which D term feeds W_c_fk[k] (rpf.cpp:464 reads a 3-array at k<12: UB) */
 enum {
@@ -68,6 +69,12 @@ typedef struct rpf_oracle_desc {
     double sigma_seed; /* rpf.cpp:533 : 0.002 */
     int32_t n_threads; /* 0 = all cores (OpenMP) */
     int32_t reserved;
+    /* sample-vector layout: columns [0,2) pFilm | [2,5) colour | [5,5+n_random) random parameters | then n_feat
+     * features.  0 = the reference's (2 and 12: sd.h:21-49).  Debug planes are sized 5+n_random+n_feat columns,
+     * n_feat*(n_random+2) + 3*(n_random+2+n_feat) MI pairs (rpf.cpp:416-442 with the loop bounds generalised), n_feat betas.
+     * planes stay fp32 on this side: an fp16-stored buffer is checked on its (exactly representable) fp32 image. */
+    int32_t n_random;
+    int32_t n_feat;
 } rpf_oracle_desc;
 
 /* optional per-pixel debug planes; any pointer may be NULL. Indexed [y*W+x] (rows outside
@@ -131,8 +138,9 @@ void rpf_oracle_pixel_mean(const rpf_oracle_desc *d, const double *colour, const
  * maximum over the image (maximum starts at 0; a zero maximum gives 0, vis.h:32-37). out = 6 images back to back. */
 void rpf_oracle_feature_images(const rpf_oracle_desc *d, const float *planes, double *out);
 
-/* pair order of the 96 MI values (a,b column indices in the 19-vector) */
+/* pair order of the 96 MI values (a,b column indices in the 19-vector); _ex: any layout, npair entries */
 void rpf_oracle_pair_table(int32_t a[RPF_O_NPAIR], int32_t b[RPF_O_NPAIR]);
+void rpf_oracle_pair_table_ex(int32_t n_random, int32_t n_feat, int32_t *a, int32_t *b);
 
 #ifdef __cplusplus
 }

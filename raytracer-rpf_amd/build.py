@@ -4,12 +4,14 @@ fp64 operation order for the discrete decisions (see csrc/rpf_kernels.hip)."""
 import os
 import shutil
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB = os.path.join(_HERE, "lib", "librpf_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("rpf_kernels.hip", "rpf_api.hip")]
 HEADERS = [os.path.join(_HERE, "csrc", "rpf_internal.h"), os.path.join(_HERE, "csrc", "rpf_xlane.h"),
+           os.path.join(_HERE, "csrc", "rpf_filter_impl.inc"),
            os.path.join(_ROOT, "include", "rpf_hip.h")]
 
 
@@ -17,19 +19,48 @@ def hipcc_path():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+OBJ_DIR = os.path.join(_ROOT, "build", "obj")
+
+
+def _stale(target, deps):
+    return (not os.path.exists(target)) or any(os.path.getmtime(f) > os.path.getmtime(target) for f in deps)
+
+
 def is_stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS)
+    return _stale(LIB, SOURCES + HEADERS)
 
 
 def build(force=False, verbose=False):
+    """one object per translation unit (the kernel TU takes minutes, the ABI TU seconds), then the link"""
     if not force and not is_stale():
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-           "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc"), "-o", LIB] + SOURCES
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
+             "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc")]
+    objs, procs = [], []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + HEADERS):
+            # -save-temps=obj keeps the device assembly next to the object: scripts/check_spills.py reads it below
+            cmd = [hipcc_path()] + flags + ["-save-temps=obj", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    import glob
+    asm = [f for f in glob.glob(os.path.join(OBJ_DIR, "*gfx950*.s")) if "rpf_kernels" in os.path.basename(f)]
+    if asm:
+        chk = subprocess.run([sys.executable, os.path.join(_ROOT, "scripts", "check_spills.py")] + asm,
+                             stdout=subprocess.PIPE, text=True)
+        if chk.returncode != 0:
+            raise RuntimeError("miscompiled spill placement in the kernel TU (see scripts/check_spills.py):\n" + chk.stdout)
+        if verbose:
+            print(chk.stdout)
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rpf_internal.h"
@@ -22,7 +23,7 @@ struct rpf_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     // grow-only HBM workspace
-    float *d_planes = nullptr;   size_t cap_planes = 0;   // 19 planes fp32
+    char *d_planes = nullptr;    size_t cap_planes = 0;   // ndim planes of fp32 (or fp16)
     float *d_rayw = nullptr;     size_t cap_rayw = 0;
     double *d_colA = nullptr;    size_t cap_colA = 0;     // 3 planes fp64
     double *d_colB = nullptr;    size_t cap_colB = 0;
@@ -80,6 +81,17 @@ int32_t ensure(rpf_ctx *ctx, T *&ptr, size_t &cap, size_t bytes) {
     return RPF_OK;
 }
 
+// the sample-vector layout a descriptor names (0 in all three fields = the reference's 19 dims, fp32 planes)
+SampleLayout layout_of(const rpf_desc *d) {
+    SampleLayout l;
+    if (d->n_random != 0 || d->n_feat != 0 || d->plane_dtype != 0) {
+        l.nR = d->n_random ? d->n_random : 2;
+        l.nF = d->n_feat ? d->n_feat : 12;
+        l.f16 = d->plane_dtype == RPF_PLANES_F16 ? 1 : (d->plane_dtype == RPF_PLANES_F32 ? 0 : -1);
+    }
+    return l;
+}
+
 int32_t validate(rpf_ctx *ctx, const rpf_desc *d, bool need_boxes) {
     if (!ctx) return RPF_E_BADARG;
     if (!d) return fail(ctx, RPF_E_BADARG, "desc is NULL");
@@ -89,6 +101,9 @@ int32_t validate(rpf_ctx *ctx, const rpf_desc *d, bool need_boxes) {
     if ((uint64_t)d->W * d->H * d->S >= (1ull << 32))
         return fail(ctx, RPF_E_BADARG, "W*H*S must be < 2^32 per slab (split the image into row slabs)");
     if (d->beta_map < 0 || d->beta_map > RPF_BETA_PAPER) return fail(ctx, RPF_E_BADARG, "unknown beta_map");
+    if (!layout_of(d).supported())
+        return fail(ctx, RPF_E_UNSUPPORTED, "sample layout: kernels exist for n_random=2, n_feat=12, fp32 planes (the reference's "
+                                            "19 dims) and n_random=4, n_feat=18, fp16 planes (27 dims)");
     if (d->degenerate_policy < 0 || d->degenerate_policy > RPF_DEGEN_EPS)
         return fail(ctx, RPF_E_BADARG, "unknown degenerate_policy");
     if (need_boxes) {
@@ -129,12 +144,14 @@ struct PassSetup {
     uint32_t lds = 0;
 };
 
-int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const float *d_planes, const double *col_in,
+int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const void *d_planes, const double *col_in,
                    double *col_out, const rpf_debug *dbg_dev, PassSetup &out) {
     if (box < 1 || (box & 1) == 0) return fail(ctx, RPF_E_BADARG, "box must be odd and positive");
     PassParams &p = out.p;
     std::memset(&p, 0, sizeof(p));
     p.W = d->W; p.H = d->H; p.S = d->S;
+    p.lay = layout_of(d);
+    const int kNFeat = p.lay.nF;
     p.row_begin = d->row_begin; p.row_end = d->row_end;
     p.box = box; p.b = (box - 1) / 2;
     p.beta_map = d->beta_map; p.policy = d->degenerate_policy;
@@ -158,7 +175,7 @@ int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const float *d_plan
     p.pmean = ctx->d_pmean; p.pstd = ctx->d_pstd; p.tfix = ctx->d_tfix; p.dfix = ctx->d_dfix;
     p.nbhd = ctx->d_nbhd; p.status = ctx->d_status;
     if (dbg_dev) p.dbg = *dbg_dev;
-    out.lds = lds_layout(p.S, p.nmax, p.bmax, table_in_lds(p.S, p.nmax, p.bmax, ctx->tun), ctx->tun).total;
+    out.lds = lds_layout(p.S, p.nmax, p.bmax, table_in_lds(p.S, p.nmax, p.bmax, ctx->tun, p.lay), ctx->tun, p.lay).total;
     if ((int)out.lds > max_lds_per_block())
         return fail(ctx, RPF_E_UNSUPPORTED, "neighbourhood working set exceeds 160 KiB of LDS");
     return RPF_OK;
@@ -216,7 +233,7 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p, hipStream_t s, i
 }
 
 // runs all passes of desc on device-resident buffers; colour ends up in d_colour
-int32_t run_passes(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, double *d_colour, hipStream_t s) {
+int32_t run_passes(rpf_ctx *ctx, const rpf_desc *d, const void *d_planes, double *d_colour, hipStream_t s) {
     const bool timing = (d->flags & RPF_FLAG_TIMING) != 0;
     const size_t ps = (size_t)d->W * d->H * d->S;
     int32_t st;
@@ -313,10 +330,14 @@ int32_t finish_counters(rpf_ctx *ctx, const rpf_desc *d, hipStream_t s) {
     return RPF_OK;
 }
 
-int32_t run_host_pipeline(rpf_ctx *ctx, const rpf_desc *d, const float *planes, const float *ray_weight,
+int32_t run_host_pipeline(rpf_ctx *ctx, const rpf_desc *d, const void *planes_v, const float *ray_weight,
                           float *sample_rgb_out, float *pixel_rgb_out) {
     const int W = d->W, H = d->H, S = d->S;
     const size_t row = (size_t)W * S, ps = row * H;
+    const SampleLayout lay = layout_of(d);
+    const int kNDim = lay.ndim();
+    const size_t pb = lay.plane_bytes();
+    const char *planes = static_cast<const char *>(planes_v);
     hipStream_t s = ctx->stream, up = ctx->s_up, down = ctx->s_down;
     int32_t st;
     ctx->bin_valid = false;
@@ -389,13 +410,13 @@ int32_t run_host_pipeline(rpf_ctx *ctx, const rpf_desc *d, const float *planes, 
                 if (first) {
                     const size_t o = (size_t)bd.r0 * row, n = (size_t)(bd.r1 - bd.r0) * row;
                     for (int k = 0; k < kNDim; ++k)
-                        HIP_TRY(hipMemcpyAsync(ctx->d_planes + k * ps + o, planes + k * ps + o, n * sizeof(float),
+                        HIP_TRY(hipMemcpyAsync(ctx->d_planes + (k * ps + o) * pb, planes + (k * ps + o) * pb, n * pb,
                                                hipMemcpyHostToDevice, up));
                     if (ray_weight)
                         HIP_TRY(hipMemcpyAsync(ctx->d_rayw + o, ray_weight + o, n * sizeof(float), hipMemcpyHostToDevice, up));
                     HIP_TRY(hipEventRecord(ev_up[j], up));
                     HIP_TRY(hipStreamWaitEvent(s, ev_up[j], 0));
-                    HIP_TRY(launch_colour_from_planes_span(ctx->d_planes, cin, ps, o, n, s));
+                    HIP_TRY(launch_colour_from_planes_span(ctx->d_planes, lay.f16 != 0, cin, ps, o, n, s));
                     HIP_TRY(launch_pixel_stats_rows(ps_.p, bd.r0, bd.r1, s));
                     if (j >= 1) { // band j-1 has its lower halo now
                         if ((st = filter_rows(bands[j - 1].r0, bands[j - 1].r1))) return st;
@@ -491,17 +512,18 @@ int64_t rpf_lds_bytes_required(int32_t S, int32_t box) {
     int bmax = (int)std::sqrt((double)nm);
     if (bmax < 1) bmax = 1;
     const Tuning tun;
-    return lds_layout(S, nm, bmax, table_in_lds(S, nm, bmax, tun), tun).total;
+    const SampleLayout lay;
+    return lds_layout(S, nm, bmax, table_in_lds(S, nm, bmax, tun, lay), tun, lay).total;
 }
 
-int32_t rpf_colour_from_planes_device(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, double *d_colour,
+int32_t rpf_colour_from_planes_device(rpf_ctx *ctx, const rpf_desc *d, const void *d_planes, double *d_colour,
                                       void *stream) {
     int32_t st = validate(ctx, d, false);
     if (st) return st;
     if (!d_planes || !d_colour) return fail(ctx, RPF_E_BADARG, "NULL device pointer");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream; // NULL = the legacy default stream: ordered after the caller's own work
-    HIP_TRY(launch_colour_from_planes(d_planes, d_colour, (uint64_t)d->W * d->H * d->S, s));
+    HIP_TRY(launch_colour_from_planes(d_planes, layout_of(d).f16 != 0, d_colour, (uint64_t)d->W * d->H * d->S, s));
     return RPF_OK;
 }
 
@@ -516,7 +538,7 @@ int32_t rpf_reduce_device(rpf_ctx *ctx, const rpf_desc *d, const double *d_colou
     return RPF_OK;
 }
 
-int32_t rpf_filter_device(rpf_ctx *ctx, const rpf_desc *d, const float *d_planes, double *d_colour, void *stream) {
+int32_t rpf_filter_device(rpf_ctx *ctx, const rpf_desc *d, const void *d_planes, double *d_colour, void *stream) {
     int32_t st = validate(ctx, d, true);
     if (st) return st;
     if (!d_planes || !d_colour) return fail(ctx, RPF_E_BADARG, "NULL device pointer");
@@ -558,12 +580,12 @@ int32_t rpf_set_option(rpf_ctx *ctx, const char *name, int64_t value) {
     return RPF_OK;
 }
 
-int32_t rpf_filter(rpf_ctx *ctx, const rpf_desc *d, const float *planes, const float *ray_weight,
+int32_t rpf_filter(rpf_ctx *ctx, const rpf_desc *d, const void *planes, const float *ray_weight,
                    float *sample_rgb_out, float *pixel_rgb_out) {
     return rpf_filter_ex(ctx, d, planes, nullptr, ray_weight, sample_rgb_out, pixel_rgb_out, nullptr);
 }
 
-int32_t rpf_filter_ex(rpf_ctx *ctx, const rpf_desc *d, const float *planes, const double *colour64_in,
+int32_t rpf_filter_ex(rpf_ctx *ctx, const rpf_desc *d, const void *planes, const double *colour64_in,
                       const float *ray_weight, float *sample_rgb_out, float *pixel_rgb_out, double *colour64_out) {
     int32_t st = validate(ctx, d, true);
     if (st) return st;
@@ -571,7 +593,9 @@ int32_t rpf_filter_ex(rpf_ctx *ctx, const rpf_desc *d, const float *planes, cons
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const size_t ps = (size_t)d->W * d->H * d->S, HW = (size_t)d->W * d->H;
-    if ((st = ensure(ctx, ctx->d_planes, ctx->cap_planes, kNDim * ps * sizeof(float)))) return st;
+    const SampleLayout lay = layout_of(d);
+    const size_t plane_total = (size_t)lay.ndim() * ps * lay.plane_bytes();
+    if ((st = ensure(ctx, ctx->d_planes, ctx->cap_planes, plane_total))) return st;
     if ((st = ensure(ctx, ctx->d_colA, ctx->cap_colA, 3 * ps * sizeof(double)))) return st;
     if (ray_weight && (st = ensure(ctx, ctx->d_rayw, ctx->cap_rayw, ps * sizeof(float)))) return st;
     if (sample_rgb_out && (st = ensure(ctx, ctx->d_srgb, ctx->cap_srgb, 3 * ps * sizeof(float)))) return st;
@@ -590,10 +614,10 @@ int32_t rpf_filter_ex(rpf_ctx *ctx, const rpf_desc *d, const float *planes, cons
         return run_host_pipeline(ctx, d, planes, ray_weight, sample_rgb_out, pixel_rgb_out);
     // serial variant (per-kernel event timing needs it): upload, passes, download
     const double t0 = now_ms();
-    HIP_TRY(hipMemcpyAsync(ctx->d_planes, planes, kNDim * ps * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->d_planes, planes, plane_total, hipMemcpyHostToDevice, s));
     if (ray_weight) HIP_TRY(hipMemcpyAsync(ctx->d_rayw, ray_weight, ps * sizeof(float), hipMemcpyHostToDevice, s));
     if (colour64_in) HIP_TRY(hipMemcpyAsync(ctx->d_colA, colour64_in, 3 * ps * sizeof(double), hipMemcpyHostToDevice, s));
-    else HIP_TRY(launch_colour_from_planes(ctx->d_planes, ctx->d_colA, ps, s));
+    else HIP_TRY(launch_colour_from_planes(ctx->d_planes, lay.f16 != 0, ctx->d_colA, ps, s));
     HIP_TRY(hipStreamSynchronize(s));
     const double t1 = now_ms();
     const int32_t fst = run_passes(ctx, d, ctx->d_planes, ctx->d_colA, s);
@@ -617,18 +641,22 @@ int32_t rpf_filter_ex(rpf_ctx *ctx, const rpf_desc *d, const float *planes, cons
     return fst;
 }
 
-int32_t rpf_stage_pixel_stats(rpf_ctx *ctx, const rpf_desc *d, const float *planes, double *mean, double *stddev) {
+int32_t rpf_stage_pixel_stats(rpf_ctx *ctx, const rpf_desc *d, const void *planes, double *mean, double *stddev) {
     int32_t st = validate(ctx, d, false);
     if (st) return st;
     if (!planes || !mean || !stddev) return fail(ctx, RPF_E_BADARG, "NULL pointer");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const size_t ps = (size_t)d->W * d->H * d->S, HW = (size_t)d->W * d->H;
-    if ((st = ensure(ctx, ctx->d_planes, ctx->cap_planes, kNDim * ps * sizeof(float)))) return st;
+    const SampleLayout lay = layout_of(d);
+    const int kNFeat = lay.nF;
+    const size_t plane_total = (size_t)lay.ndim() * ps * lay.plane_bytes();
+    if ((st = ensure(ctx, ctx->d_planes, ctx->cap_planes, plane_total))) return st;
     if ((st = ensure(ctx, ctx->d_pmean, ctx->cap_pmean, HW * kNFeat * sizeof(double)))) return st;
     if ((st = ensure(ctx, ctx->d_pstd, ctx->cap_pstd, HW * kNFeat * sizeof(double)))) return st;
-    HIP_TRY(hipMemcpyAsync(ctx->d_planes, planes, kNDim * ps * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->d_planes, planes, plane_total, hipMemcpyHostToDevice, s));
     PassParams p{};
+    p.lay = lay;
     p.W = d->W; p.H = d->H; p.S = d->S; p.policy = d->degenerate_policy;
     p.plane_stride = ps; p.planes = ctx->d_planes; p.pmean = ctx->d_pmean; p.pstd = ctx->d_pstd;
     HIP_TRY(launch_pixel_stats(p, s));
@@ -644,7 +672,7 @@ int32_t rpf_stage_pixel_stats(rpf_ctx *ctx, const rpf_desc *d, const float *plan
     return RPF_OK;
 }
 
-int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *d, int32_t box, const float *planes,
+int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *d, int32_t box, const void *planes,
                               const double *colour_in, double *colour_out, const rpf_debug *dbg) {
     int32_t st = validate(ctx, d, false);
     if (st) return st;
@@ -652,14 +680,17 @@ int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *d, int32_t box, cons
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const size_t ps = (size_t)d->W * d->H * d->S, HW = (size_t)d->W * d->H;
-    if ((st = ensure(ctx, ctx->d_planes, ctx->cap_planes, kNDim * ps * sizeof(float)))) return st;
+    const SampleLayout lay = layout_of(d);
+    const size_t kNDim = (size_t)lay.ndim(), kNFeat = (size_t)lay.nF, kNPair = (size_t)lay.npair();
+    const size_t plane_total = kNDim * ps * lay.plane_bytes();
+    if ((st = ensure(ctx, ctx->d_planes, ctx->cap_planes, plane_total))) return st;
     if ((st = ensure(ctx, ctx->d_colA, ctx->cap_colA, 3 * ps * sizeof(double)))) return st;
     if ((st = ensure(ctx, ctx->d_colB, ctx->cap_colB, 3 * ps * sizeof(double)))) return st;
-    HIP_TRY(hipMemcpyAsync(ctx->d_planes, planes, kNDim * ps * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ctx->d_planes, planes, plane_total, hipMemcpyHostToDevice, s));
     if (colour_in)
         HIP_TRY(hipMemcpyAsync(ctx->d_colA, colour_in, 3 * ps * sizeof(double), hipMemcpyHostToDevice, s));
     else
-        HIP_TRY(launch_colour_from_planes(ctx->d_planes, ctx->d_colA, ps, s));
+        HIP_TRY(launch_colour_from_planes(ctx->d_planes, lay.f16 != 0, ctx->d_colA, ps, s));
     // debug planes
     const size_t dbg_bytes[9] = {HW * 4, HW * kNDim * 8, HW * kNDim * 8, HW * kNPair * 8, HW * 3 * 8,
                                  HW * kNFeat * 8, HW * 8, HW * kNDim * 4, HW * 4};
@@ -718,19 +749,21 @@ int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *d, int32_t box, cons
     return RPF_OK;
 }
 
-int32_t rpf_feature_images(rpf_ctx *ctx, const rpf_desc *d, const float *planes, double *images_out) {
+int32_t rpf_feature_images(rpf_ctx *ctx, const rpf_desc *d, const void *planes, double *images_out) {
     int32_t st = validate(ctx, d, false);
     if (st) return st;
     if (!planes || !images_out) return fail(ctx, RPF_E_BADARG, "NULL pointer");
+    if (!layout_of(d).is_ref19()) return fail(ctx, RPF_E_UNSUPPORTED, "visualizeSF's six images are defined for the reference's 19-dim layout");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const size_t ps = (size_t)d->W * d->H * d->S, HW = (size_t)d->W * d->H;
+    const size_t kNDim = RPF_NDIM;
     if ((st = ensure(ctx, ctx->d_planes, ctx->cap_planes, kNDim * ps * sizeof(float)))) return st;
     if ((st = ensure(ctx, ctx->d_dbg[1], ctx->cap_dbg[1], (18 * HW + 18) * sizeof(double)))) return st;
     double *d_img = (double *)ctx->d_dbg[1];
     unsigned long long *d_max = (unsigned long long *)(d_img + 18 * HW);
     HIP_TRY(hipMemcpyAsync(ctx->d_planes, planes, kNDim * ps * sizeof(float), hipMemcpyHostToDevice, s));
-    HIP_TRY(launch_feature_images(ctx->d_planes, d->W, d->H, d->S, d_img, d_max, s));
+    HIP_TRY(launch_feature_images(reinterpret_cast<const float *>(ctx->d_planes), d->W, d->H, d->S, d_img, d_max, s));
     HIP_TRY(hipMemcpyAsync(images_out, d_img, 18 * HW * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return RPF_OK;
@@ -751,6 +784,283 @@ int32_t rpf_selftest_udiv(rpf_ctx *ctx, uint64_t n, uint64_t seed, int32_t mode,
 int32_t rpf_query_counters(rpf_ctx *ctx, rpf_counters *out) {
     if (!ctx || !out) return RPF_E_BADARG;
     *out = ctx->counters;
+    return RPF_OK;
+}
+
+} // extern "C"
+
+// ---- one process, several GPUs: row slabs behind the ABI ---------------------------------------------------------
+// The reference's caller is one process (RPFIntegrator::Render, rpf.cpp:737-805); rpf_multi lets that one caller use
+// every GPU of the node.  The image is cut into contiguous row slabs, one per entry of `devices` (an entry may repeat:
+// two slabs on one GPU rehearse the multi-GPU path on a one-GPU box); slab g holds its rows plus `halo` rows of each
+// neighbour, halo = max over the box list of (box-1)/2 (rpf.cpp:561).  Features never change, so their halo travels
+// with the upload; colours change every pass, so before pass i >= 1 every slab's halo rows are refreshed from the
+// neighbour's OWNED boundary rows with hipMemcpyPeerAsync (xGMI when peer access is available, staged otherwise; a
+// plain device copy when both slabs share a GPU).  Passes run concurrently, one host thread per slab.
+struct rpf_multi {
+    std::vector<rpf_ctx *> ctx;
+    std::vector<int> dev;
+    std::string err;
+    rpf_counters counters{};
+};
+
+namespace {
+
+struct MSlab { int a, b, ht, hb; int rows() const { return ht + (b - a) + hb; } }; // owned image rows [a,b), halo rows held
+
+int32_t mfail(rpf_multi *m, int32_t st, const std::string &msg) {
+    if (m) m->err = msg;
+    return st;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t rpf_multi_create(rpf_multi **out, const int32_t *devices, int32_t n_devices) {
+    if (!out) return RPF_E_BADARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RPF_E_NODEVICE;
+    rpf_multi *m = new rpf_multi();
+    *out = m; // returned even on failure so that rpf_multi_last_error() can be read
+    std::vector<int> devs;
+    if (devices && n_devices > 0) devs.assign(devices, devices + n_devices);
+    else for (int i = 0; i < n; ++i) devs.push_back(i); // NULL / 0: every visible device
+    for (int d : devs) {
+        rpf_ctx *c = nullptr;
+        const int32_t st = rpf_create(&c, d);
+        if (st != RPF_OK) {
+            const std::string e = c ? c->err : std::string("no such device");
+            if (c) rpf_destroy(c);
+            return mfail(m, st, "rpf_create(device " + std::to_string(d) + "): " + e);
+        }
+        m->ctx.push_back(c);
+        m->dev.push_back(d);
+    }
+    // direct peer copies between neighbouring slabs where the hardware offers them (failure = staged copies: still correct)
+    for (size_t g = 0; g + 1 < devs.size(); ++g) {
+        const int a = devs[g], b = devs[g + 1];
+        if (a == b) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) { (void)hipSetDevice(a); (void)hipDeviceEnablePeerAccess(b, 0); }
+        if (hipDeviceCanAccessPeer(&can, b, a) == hipSuccess && can) { (void)hipSetDevice(b); (void)hipDeviceEnablePeerAccess(a, 0); }
+        (void)hipGetLastError(); // "already enabled" is not an error here
+    }
+    return RPF_OK;
+}
+
+void rpf_multi_destroy(rpf_multi *m) {
+    if (!m) return;
+    for (rpf_ctx *c : m->ctx) rpf_destroy(c);
+    delete m;
+}
+
+const char *rpf_multi_last_error(const rpf_multi *m) { return m ? m->err.c_str() : "multi context is NULL"; }
+int32_t rpf_multi_device_count(const rpf_multi *m) { return m ? (int32_t)m->ctx.size() : 0; }
+
+int32_t rpf_multi_set_option(rpf_multi *m, const char *name, int64_t value) {
+    if (!m) return RPF_E_BADARG;
+    for (rpf_ctx *c : m->ctx) {
+        const int32_t st = rpf_set_option(c, name, value);
+        if (st != RPF_OK) return mfail(m, st, c->err);
+    }
+    return RPF_OK;
+}
+
+int32_t rpf_multi_query_counters(rpf_multi *m, rpf_counters *out) {
+    if (!m || !out) return RPF_E_BADARG;
+    *out = m->counters;
+    return RPF_OK;
+}
+
+int32_t rpf_multi_filter(rpf_multi *m, const rpf_desc *d, const void *planes_v, const float *ray_weight,
+                         float *sample_rgb_out, float *pixel_rgb_out) {
+    if (!m || m->ctx.empty()) return RPF_E_BADARG;
+    {
+        const int32_t st = validate(m->ctx[0], d, true);
+        if (st != RPF_OK) return mfail(m, st, m->ctx[0]->err);
+    }
+    if (!planes_v) return mfail(m, RPF_E_BADARG, "planes is NULL");
+    if (d->row_begin != 0 || d->row_end != d->H)
+        return mfail(m, RPF_E_BADARG, "rpf_multi_filter filters the whole image (row_begin = 0, row_end = H): the slabs are its own");
+    const int G = (int)m->ctx.size(), W = d->W, H = d->H, S = d->S;
+    int halo = 0;
+    for (int i = 0; i < d->n_box; ++i) halo = std::max(halo, (d->box_sizes[i] - 1) / 2);
+    std::vector<MSlab> sl(G);
+    for (int g = 0; g < G; ++g) {
+        sl[g].a = (int)((int64_t)g * H / G);
+        sl[g].b = (int)((int64_t)(g + 1) * H / G);
+        sl[g].ht = std::min(halo, sl[g].a);
+        sl[g].hb = std::min(halo, H - sl[g].b);
+        if (G > 1 && sl[g].b - sl[g].a < halo)
+            return mfail(m, RPF_E_BADARG, "a row slab is thinner than the halo its neighbours need (H / devices < (box-1)/2): use fewer devices");
+    }
+    const SampleLayout lay = layout_of(d);
+    const int ND = lay.ndim();
+    const size_t pb = lay.plane_bytes(), row = (size_t)W * S, ps_img = row * H;
+    const char *planes = static_cast<const char *>(planes_v);
+    std::vector<double *> cin(G), cout(G);
+    std::vector<int32_t> status(G, RPF_OK);
+    std::vector<rpf_desc> sd(G, *d);
+
+    // ---- upload: every slab's rows (+ halo rows) of every plane; colours seeded on the device ------------------------
+    auto per_slab = [&](auto &&fn) {
+        std::vector<std::thread> th;
+        for (int g = 0; g < G; ++g) th.emplace_back([&, g] { status[g] = fn(g); });
+        for (auto &t : th) t.join();
+        for (int g = 0; g < G; ++g)
+            if (status[g] != RPF_OK && status[g] != RPF_E_NONFINITE) return mfail(m, status[g], "slab " + std::to_string(g) + ": " + m->ctx[g]->err);
+        return (int32_t)RPF_OK;
+    };
+    int32_t st = per_slab([&](int g) -> int32_t {
+        rpf_ctx *ctx = m->ctx[g];
+        HIP_TRY(hipSetDevice(ctx->device));
+        const MSlab &q = sl[g];
+        const size_t ps = row * q.rows(), HW = (size_t)W * q.rows();
+        rpf_desc &ds = sd[g];
+        ds.H = q.rows(); ds.row_begin = q.ht; ds.row_end = q.ht + (q.b - q.a); ds.n_box = 1;
+        int32_t e;
+        if ((e = ensure(ctx, ctx->d_planes, ctx->cap_planes, (size_t)ND * ps * pb))) return e;
+        if ((e = ensure(ctx, ctx->d_colA, ctx->cap_colA, 3 * ps * sizeof(double)))) return e;
+        if ((e = ensure(ctx, ctx->d_colB, ctx->cap_colB, 3 * ps * sizeof(double)))) return e;
+        if (ray_weight && (e = ensure(ctx, ctx->d_rayw, ctx->cap_rayw, ps * sizeof(float)))) return e;
+        if (sample_rgb_out && (e = ensure(ctx, ctx->d_srgb, ctx->cap_srgb, 3 * ps * sizeof(float)))) return e;
+        if (pixel_rgb_out && (e = ensure(ctx, ctx->d_prgb, ctx->cap_prgb, 3 * HW * sizeof(float)))) return e;
+        hipStream_t s = ctx->stream;
+        const size_t o = (size_t)(q.a - q.ht) * row;
+        for (int k = 0; k < ND; ++k)
+            HIP_TRY(hipMemcpyAsync(ctx->d_planes + (size_t)k * ps * pb, planes + ((size_t)k * ps_img + o) * pb, ps * pb,
+                                   hipMemcpyHostToDevice, s));
+        if (ray_weight) HIP_TRY(hipMemcpyAsync(ctx->d_rayw, ray_weight + o, ps * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(launch_colour_from_planes(ctx->d_planes, lay.f16 != 0, ctx->d_colA, ps, s));
+        const int32_t init_status[2] = {0, INT_MAX};
+        HIP_TRY(hipMemcpyAsync(ctx->d_status, init_status, sizeof(init_status), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        ctx->bin_valid = false;
+        ctx->counters = rpf_counters{};
+        cin[g] = ctx->d_colA; cout[g] = ctx->d_colB;
+        return RPF_OK;
+    });
+    if (st != RPF_OK) return st;
+
+    float ms_filter = 0.f;
+    int launches = 0;
+    for (int i = 0; i < d->n_box; ++i) {
+        const int box = d->box_sizes[i];
+        // ---- colour halo refresh from the neighbours' owned rows (pass 0: the upload already carried it) ----------
+        if (i > 0 && G > 1) {
+            for (int g = 0; g + 1 < G; ++g) {
+                rpf_ctx *up = m->ctx[g], *dn = m->ctx[g + 1];
+                const size_t ps_u = row * sl[g].rows(), ps_d = row * sl[g + 1].rows();
+                const size_t hb = (size_t)sl[g].hb * row, ht = (size_t)sl[g + 1].ht * row; // == halo rows on both sides
+                for (int c = 0; c < 3; ++c) {
+                    // bottom halo of slab g <- first owned rows of slab g+1
+                    const double *src1 = cin[g + 1] + c * ps_d + (size_t)sl[g + 1].ht * row;
+                    double *dst1 = cin[g] + c * ps_u + (size_t)(sl[g].ht + sl[g].b - sl[g].a) * row;
+                    // top halo of slab g+1 <- last owned rows of slab g
+                    const double *src2 = cin[g] + c * ps_u + (size_t)(sl[g].ht + sl[g].b - sl[g].a) * row - ht;
+                    double *dst2 = cin[g + 1] + c * ps_d;
+                    hipError_t e1, e2;
+                    if (up->device == dn->device) {
+                        (void)hipSetDevice(up->device);
+                        e1 = hipMemcpyAsync(dst1, src1, hb * sizeof(double), hipMemcpyDeviceToDevice, up->stream);
+                        e2 = hipMemcpyAsync(dst2, src2, ht * sizeof(double), hipMemcpyDeviceToDevice, up->stream);
+                    } else {
+                        e1 = hipMemcpyPeerAsync(dst1, up->device, src1, dn->device, hb * sizeof(double), up->stream);
+                        e2 = hipMemcpyPeerAsync(dst2, dn->device, src2, up->device, ht * sizeof(double), dn->stream);
+                    }
+                    if (e1 != hipSuccess || e2 != hipSuccess)
+                        return mfail(m, RPF_E_HIP, std::string("halo copy: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+                }
+            }
+            for (int g = 0; g < G; ++g) { // every copy has landed before any slab starts the pass
+                (void)hipSetDevice(m->ctx[g]->device);
+                if (hipStreamSynchronize(m->ctx[g]->stream) != hipSuccess) return mfail(m, RPF_E_HIP, "halo copy synchronise");
+            }
+        }
+        // ---- the pass, all slabs concurrently ------------------------------------------------------------------------
+        std::vector<float> ms(G, 0.f);
+        std::vector<int> nl(G, 0);
+        st = per_slab([&](int g) -> int32_t {
+            rpf_ctx *ctx = m->ctx[g];
+            HIP_TRY(hipSetDevice(ctx->device));
+            hipStream_t s = ctx->stream;
+            const MSlab &q = sl[g];
+            const size_t ps = row * q.rows();
+            PassSetup pp;
+            int32_t e;
+            if ((e = setup_pass(ctx, &sd[g], box, ctx->d_planes, cin[g], cout[g], nullptr, pp))) return e;
+            // halo rows pass through (they are refreshed from the neighbour before the next pass)
+            HIP_TRY(launch_copy_colour_span(cin[g], cout[g], ps, 0, (uint64_t)q.ht * row, s));
+            HIP_TRY(launch_copy_colour_span(cin[g], cout[g], ps, (uint64_t)(q.ht + q.b - q.a) * row, (uint64_t)q.hb * row, s));
+            if (i == 0) HIP_TRY(launch_pixel_stats(pp.p, s)); // stage 1a depends on the features only
+            HIP_TRY(hipEventRecord(ctx->ev[0], s));
+            if ((e = launch_filter_binned(ctx, pp.p, s, &nl[g]))) return e;
+            HIP_TRY(hipEventRecord(ctx->ev[1], s));
+            HIP_TRY(hipEventSynchronize(ctx->ev[1]));
+            HIP_TRY(hipEventElapsedTime(&ms[g], ctx->ev[0], ctx->ev[1]));
+            return RPF_OK;
+        });
+        if (st != RPF_OK) return st;
+        float mx = 0.f;
+        for (int g = 0; g < G; ++g) { mx = std::max(mx, ms[g]); launches += nl[g]; std::swap(cin[g], cout[g]); }
+        ms_filter += mx;
+    }
+
+    // ---- reduce + download the owned rows; merge status and counters -----------------------------------------------
+    rpf_counters tot{};
+    tot.first_bad_pixel = -1;
+    std::vector<rpf_counters> cs(G);
+    st = per_slab([&](int g) -> int32_t {
+        rpf_ctx *ctx = m->ctx[g];
+        HIP_TRY(hipSetDevice(ctx->device));
+        hipStream_t s = ctx->stream;
+        const MSlab &q = sl[g];
+        const size_t ps = row * q.rows(), own0 = (size_t)q.ht * row, own_n = (size_t)(q.b - q.a) * row;
+        HIP_TRY(hipMemsetAsync(ctx->d_nred, 0, 2 * sizeof(unsigned long long), s));
+        if (sample_rgb_out || pixel_rgb_out) {
+            HIP_TRY(launch_reduce_rows(cin[g], ray_weight ? ctx->d_rayw : nullptr, sample_rgb_out ? ctx->d_srgb : nullptr,
+                                       pixel_rgb_out ? ctx->d_prgb : nullptr, W, q.rows(), S, q.ht, q.ht + (q.b - q.a), s));
+            if (sample_rgb_out)
+                for (int c = 0; c < 3; ++c)
+                    HIP_TRY(hipMemcpyAsync(sample_rgb_out + c * ps_img + (size_t)q.a * row, ctx->d_srgb + c * ps + own0,
+                                           own_n * sizeof(float), hipMemcpyDeviceToHost, s));
+            if (pixel_rgb_out)
+                HIP_TRY(hipMemcpyAsync(pixel_rgb_out + (size_t)q.a * W * 3, ctx->d_prgb + (size_t)q.ht * W * 3,
+                                       (size_t)(q.b - q.a) * W * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+        }
+        rpf_desc one = sd[g];
+        one.n_box = d->n_box; // samples_filtered counts every pass
+        const int32_t fst = finish_counters(ctx, &one, s); // synchronises
+        cs[g] = ctx->counters;
+        return fst;
+    });
+    if (st != RPF_OK) return st;
+    bool bad = false;
+    for (int g = 0; g < G; ++g) {
+        const rpf_counters &c = cs[g];
+        tot.samples_filtered += c.samples_filtered;
+        tot.sum_nbhd += c.sum_nbhd;
+        tot.nonfinite_pixels += c.nonfinite_pixels;
+        tot.max_nbhd = std::max(tot.max_nbhd, c.max_nbhd);
+        tot.options_active |= c.options_active;
+        if (c.first_bad_pixel >= 0) { // slab-local y*W+x -> image index
+            const int yl = c.first_bad_pixel / W, x = c.first_bad_pixel % W;
+            const int gi = (sl[g].a - sl[g].ht + yl) * W + x;
+            if (tot.first_bad_pixel < 0 || gi < tot.first_bad_pixel) tot.first_bad_pixel = gi;
+        }
+        bad = bad || status[g] == RPF_E_NONFINITE;
+    }
+    tot.filter_kernel_ms = ms_filter; // per pass: the slowest slab
+    tot.filter_kernel_launches = launches;
+    m->counters = tot;
+    if (bad) {
+        char buf[160];
+        std::snprintf(buf, sizeof(buf), "non-finite filtered colour at pixel (x=%d, y=%d); %lld pixel(s) affected (the reference exits here, "
+                      "rpf.cpp:702-705)", tot.first_bad_pixel % W, tot.first_bad_pixel / W, (long long)tot.nonfinite_pixels);
+        return mfail(m, RPF_E_NONFINITE, buf);
+    }
     return RPF_OK;
 }
 

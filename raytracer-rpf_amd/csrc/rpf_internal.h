@@ -7,11 +7,20 @@
 
 namespace rpf {
 
-constexpr int kNDim = RPF_NDIM;   // 19
-constexpr int kNFeat = RPF_NFEAT; // 12
-constexpr int kNPair = RPF_NPAIR; // 96
-constexpr int kColP = 0, kColC = 2, kColR = 5, kColF = 7;
 constexpr int kWave = 64;
+
+// Which sample-vector layout a call uses (rpf_desc n_random / n_feat / plane_dtype).  Columns: [0,2) pFilm | [2,5) colour
+// | [5,5+nR) random parameters | [5+nR, 5+nR+nF) features (sd.h:62-94 is nR = 2, nF = 12).  The kernels exist for the
+// reference layout with fp32 planes and for BASELINE configs[4]'s 27 dims (nR = 4, nF = 18) with fp16 planes.
+struct SampleLayout {
+    int32_t nR = 2, nF = 12, f16 = 0;
+    int ndim() const { return 5 + nR + nF; }
+    int npair() const { return nF * (nR + 2) + 3 * (nR + 2 + nF); } // rpf.cpp:416-442 generalised
+    int nwt() const { return 5 + nF; }                              // weighted columns of stage 4
+    size_t plane_bytes() const { return f16 ? 2 : 4; }
+    bool is_ref19() const { return nR == 2 && nF == 12 && !f16; }
+    bool supported() const { return is_ref19() || (nR == 4 && nF == 18 && f16 == 1); }
+};
 constexpr int kStageChunk = 64; // samples gathered per step of the in-order (reference-order) sums
 constexpr int kStageHalf = 32;  // ... and staged through LDS this many at a time
 
@@ -27,7 +36,8 @@ struct PassParams {
     int32_t bmax;          // floor(sqrt(nmax)): max histogram bins per axis
     double eps, seed, sigma_p;
     uint64_t plane_stride; // H*W*S
-    const float *planes;   // 19 fp32 planes (colour planes unused)
+    SampleLayout lay;
+    const void *planes;    // ndim planes of fp32 (or fp16: lay.f16); the colour planes are only read to seed d_colour
     const double *col_in;  // 3 fp64 planes
     double *col_out;       // 3 fp64 planes
     const double *pmean;   // [12][H*W] stage 1a
@@ -60,9 +70,9 @@ struct LdsLayout {
     uint32_t hist_stride; // bytes of one wave's histogram buffer
     uint32_t nw;          // waves per pixel (1 or 4)
 };
-LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun);
+LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun, const SampleLayout &lay);
 int samples_per_lane(int nmax); // the K the filter kernel is instantiated with (0 = unsupported)
-bool table_in_lds(int S, int nmax, int bmax, const Tuning &tun);
+bool table_in_lds(int S, int nmax, int bmax, const Tuning &tun, const SampleLayout &lay);
 int waves_per_pixel(int nmax, const Tuning &tun);
 
 hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s);
@@ -73,8 +83,8 @@ constexpr int kNumClasses = 7;
 int class_capacity(int c);          // 64, 128, 256, 448, 832, 1600, 3136
 hipError_t launch_nbhd_count(const PassParams &p, hipStream_t s);
 hipError_t launch_classify(const PassParams &p, uint32_t *lists /*[7][H*W]*/, uint32_t *counts /*[7], zeroed*/, hipStream_t s);
-hipError_t launch_colour_from_planes(const float *planes, double *colour, uint64_t plane_stride, hipStream_t s);
-hipError_t launch_colour_from_planes_span(const float *planes, double *colour, uint64_t plane_stride, uint64_t e0,
+hipError_t launch_colour_from_planes(const void *planes, bool f16, double *colour, uint64_t plane_stride, hipStream_t s);
+hipError_t launch_colour_from_planes_span(const void *planes, bool f16, double *colour, uint64_t plane_stride, uint64_t e0,
                                           uint64_t cnt, hipStream_t s);
 hipError_t launch_copy_f64(const double *src, double *dst, uint64_t n, hipStream_t s);
 hipError_t launch_copy_colour_span(const double *src, double *dst, uint64_t plane_stride, uint64_t e0, uint64_t cnt,

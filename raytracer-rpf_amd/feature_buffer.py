@@ -27,6 +27,11 @@ class _NP:
     i64 = np.int64
     f32 = np.float32
     f64 = np.float64
+    f16 = np.float16
+
+    @staticmethod
+    def empty(shape, dtype):
+        return np.empty(shape, dtype)
 
     @staticmethod
     def arange(n):
@@ -46,7 +51,7 @@ class _TORCH:
         import torch
         self.t = torch
         self.device = device
-        self.i64, self.f32, self.f64 = torch.int64, torch.float32, torch.float64
+        self.i64, self.f32, self.f64, self.f16 = torch.int64, torch.float32, torch.float64, torch.float16
         self.floor, self.sqrt, self.log, self.cos, self.sin, self.where = (
             torch.floor, torch.sqrt, torch.log, torch.cos, torch.sin, torch.where)
 
@@ -55,6 +60,9 @@ class _TORCH:
 
     def stack(self, xs, axis=0):
         return self.t.stack(xs, dim=axis)
+
+    def empty(self, shape, dtype):
+        return self.t.empty(shape, dtype=dtype, device=self.device)
 
     @staticmethod
     def cast(a, dt):
@@ -89,8 +97,12 @@ def _gauss(xp, idx, seed, stream):
 
 
 def synth_planes(W, H, S, seed=20250103, sigma_f=0.05, sigma_c=1e-4, row0=0, xp=None, lens_colour=True,
-                 mode="smooth"):
-    """Synthetic feature buffer, planes [19, H, W, S] fp32 (SURVEY.md section 8d recipe).
+                 mode="smooth", n_random=2, n_feat=12, dtype="f32"):
+    """Synthetic feature buffer, planes [5 + n_random + n_feat, H, W, S] (SURVEY.md section 8d recipe); fp32, or fp16
+    with dtype="f16" (BASELINE configs[4]: fp16 feature storage).  The defaults give the reference's 19 dims.  Wider
+    layouts append: random parameters r3, r4, ... (further sample dimensions, e.g. the light sample) and features
+    13.. in groups of six -- three texture / albedo channels smooth in pFilm and three light-direction components that
+    are functions of (r3, r4) -- each with the Gaussian jitter sigma_f (clustered mode: per-sample modes instead).
 
     ``row0`` is the image row of buffer row 0 (slab generation: a rank owning rows [a,b) of a taller image
     passes row0=a and H=b-a and gets exactly the rows the single-buffer call would produce).
@@ -176,9 +188,46 @@ def synth_planes(W, H, S, seed=20250103, sigma_f=0.05, sigma_c=1e-4, row0=0, xp=
     elif mode != "smooth":
         raise ValueError("mode must be 'smooth' or 'clustered'")
 
-    cols = [fx, fy, cr, cg, cb, r1, r2, nx, ny, nz, p0x, p0y, p0z, n1x, n1y, n1z, p1x, p1y, p1z]
-    planes = xp.stack([xp.cast(c, xp.f32) for c in cols], 0)
-    return planes.reshape(NDIM, H, W, S)
+    rand = [r1, r2] + [U(5 + k) for k in range(n_random - 2)]
+    feats = [nx, ny, nz, p0x, p0y, p0z, n1x, n1y, n1z, p1x, p1y, p1z]
+    if n_feat > 12:
+        r3 = rand[2] if n_random > 2 else U(5)
+        r4 = rand[3] if n_random > 3 else U(6)
+        mc = xp.cast(r3 < 0.5, xp.f64)
+        th2, sr2 = 2.0 * math.pi * r3, xp.sqrt(r4)
+        for k in range(n_feat - 12):
+            g, j = divmod(k, 6)
+            if mode == "clustered":
+                base = (0.4 + 0.1 * j + 0.3 * ma + slow) if j < 3 else (0.2 * (j - 2) + 0.5 * mc + slow)
+            elif j < 3:
+                base = 0.5 + 0.3 * xp.sin((j + 2.0 + g) * X + (j + 0.5) * Y)
+            else:
+                base = (sr2 * xp.cos(th2), sr2 * xp.sin(th2), xp.sqrt(1.0 - r4 + 1e-12))[j - 3] * (1.0 + 0.25 * g)
+            feats.append(base + sigma_f * G(40 + k))
+    cols = [fx, fy, cr, cg, cb] + rand[:n_random] + feats[:n_feat]
+    out_dt = {"f32": xp.f32, "f16": xp.f16}[dtype]
+    # (fp16: through fp32 on every backend, so numpy and torch round identically)
+    planes = xp.stack([xp.cast(xp.cast(c, xp.f32), out_dt) for c in cols], 0)
+    return planes.reshape(5 + n_random + n_feat, H, W, S)
+
+
+def synth_planes_chunked(W, H, S, rows_per_chunk=64, row0=0, xp=None, **kw):
+    """synth_planes() for buffers too large to generate in one piece (the generator's fp64 temporaries are ~60x the
+    output): row chunks written into one preallocated buffer -- same values as the single call (global sample
+    indices).  This is how the 8192-wide x 64 spp slabs of BASELINE configs[4] are produced on the device."""
+    xp = xp or _NP
+    first = synth_planes(W, min(rows_per_chunk, H), S, row0=row0, xp=xp, **kw)
+    if H <= rows_per_chunk:
+        return first
+    out = xp.empty((first.shape[0], H, W, S), first.dtype)
+    out[:, :first.shape[1]] = first
+    del first
+    r = rows_per_chunk
+    while r < H:
+        n = min(rows_per_chunk, H - r)
+        out[:, r:r + n] = synth_planes(W, n, S, row0=row0 + r, xp=xp, **kw)
+        r += n
+    return out
 
 
 def torch_backend(device):

@@ -22,18 +22,28 @@ DEGEN_REF_ABORT, DEGEN_EPS = 0, 1
 FLAG_TIMING = 1
 FLAG_FAST_WEIGHTS = 2
 FLAG_NO_OVERLAP = 4
+PLANES_F32, PLANES_F16 = 0, 1
 
 EXPORTS = ["rpf_version", "rpf_status_string", "rpf_create", "rpf_destroy", "rpf_last_error", "rpf_filter",
            "rpf_filter_device", "rpf_colour_from_planes_device", "rpf_reduce_device", "rpf_stage_pixel_stats",
            "rpf_filter_pass_debug", "rpf_query_counters", "rpf_lds_bytes_required", "rpf_selftest_udiv", "rpf_feature_images",
-           "rpf_host_alloc", "rpf_host_free", "rpf_filter_ex", "rpf_set_option"]
+           "rpf_host_alloc", "rpf_host_free", "rpf_filter_ex", "rpf_set_option", "rpf_multi_create", "rpf_multi_destroy",
+           "rpf_multi_last_error", "rpf_multi_device_count", "rpf_multi_set_option", "rpf_multi_filter",
+           "rpf_multi_query_counters"]
 
 
 class Desc(C.Structure):
     _fields_ = [("W", C.c_int32), ("H", C.c_int32), ("S", C.c_int32), ("row_begin", C.c_int32),
                 ("row_end", C.c_int32), ("n_box", C.c_int32), ("box_sizes", C.c_int32 * MAX_BOXES),
                 ("beta_map", C.c_int32), ("degenerate_policy", C.c_int32), ("flags", C.c_int32),
-                ("eps", C.c_double), ("sigma_seed", C.c_double)]
+                ("eps", C.c_double), ("sigma_seed", C.c_double), ("n_random", C.c_int32), ("n_feat", C.c_int32),
+                ("plane_dtype", C.c_int32), ("reserved", C.c_int32)]
+
+
+def dims(desc):
+    """(ndim, nfeat, npair, numpy plane dtype) of a descriptor's sample layout (0 fields = the reference's)"""
+    nr, nf = desc.n_random or 2, desc.n_feat or 12
+    return 5 + nr + nf, nf, nf * (nr + 2) + 3 * (nr + 2 + nf), (np.float16 if desc.plane_dtype == PLANES_F16 else np.float32)
 
 
 class Debug(C.Structure):
@@ -95,6 +105,15 @@ def load():
         L.rpf_feature_images.argtypes = [C.c_void_p, C.POINTER(Desc), C.c_void_p, C.c_void_p]
         L.rpf_lds_bytes_required.restype = C.c_int64
         L.rpf_lds_bytes_required.argtypes = [C.c_int32, C.c_int32]
+        L.rpf_multi_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32]
+        L.rpf_multi_destroy.argtypes = [C.c_void_p]
+        L.rpf_multi_destroy.restype = None
+        L.rpf_multi_last_error.restype = C.c_char_p
+        L.rpf_multi_last_error.argtypes = [C.c_void_p]
+        L.rpf_multi_device_count.argtypes = [C.c_void_p]
+        L.rpf_multi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.rpf_multi_filter.argtypes = [C.c_void_p, C.POINTER(Desc)] + [C.c_void_p] * 4
+        L.rpf_multi_query_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
         L.rpf_host_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
         L.rpf_host_free.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
@@ -106,7 +125,7 @@ def status_string(st):
 
 
 def make_desc(W, H, S, boxes=(7,), row_begin=0, row_end=None, beta_map=BETA_REF_GCC11_O3, policy=DEGEN_REF_ABORT,
-              eps=1e-10, sigma_seed=0.002, flags=0):
+              eps=1e-10, sigma_seed=0.002, flags=0, n_random=0, n_feat=0, plane_dtype=PLANES_F32):
     d = Desc()
     d.W, d.H, d.S = W, H, S
     d.row_begin, d.row_end = row_begin, (H if row_end is None else row_end)
@@ -115,6 +134,7 @@ def make_desc(W, H, S, boxes=(7,), row_begin=0, row_end=None, beta_map=BETA_REF_
         d.box_sizes[i] = b
     d.beta_map, d.degenerate_policy, d.flags = beta_map, policy, flags
     d.eps, d.sigma_seed = eps, sigma_seed
+    d.n_random, d.n_feat, d.plane_dtype = n_random, n_feat, plane_dtype
     return d
 
 
@@ -177,8 +197,9 @@ class Context:
 
     def filter(self, planes, desc, ray_weight=None, want_samples=True, want_pixels=True, allow_nonfinite=False,
                out_samples=None, out_pixels=None, colour64_in=None, want_colour64=False):
-        planes = np.ascontiguousarray(planes, np.float32)
-        assert planes.shape == (NDIM, desc.H, desc.W, desc.S), planes.shape
+        nd, _, _, pdt = dims(desc)
+        planes = np.ascontiguousarray(planes, pdt)
+        assert planes.shape == (nd, desc.H, desc.W, desc.S), planes.shape
         rw = None if ray_weight is None else np.ascontiguousarray(ray_weight, np.float32)
         srgb = out_samples if out_samples is not None else (
             np.empty((3, desc.H, desc.W, desc.S), np.float32) if want_samples else None)
@@ -194,23 +215,25 @@ class Context:
         return srgb, prgb, st
 
     def pixel_stats(self, planes, desc):
-        planes = np.ascontiguousarray(planes, np.float32)
-        m = np.empty((desc.H, desc.W, NFEAT))
-        s = np.empty((desc.H, desc.W, NFEAT))
+        _, nf, _, pdt = dims(desc)
+        planes = np.ascontiguousarray(planes, pdt)
+        m = np.empty((desc.H, desc.W, nf))
+        s = np.empty((desc.H, desc.W, nf))
         self._check(self._L.rpf_stage_pixel_stats(self._h, C.byref(desc), _p(planes), _p(m), _p(s)))
         return m, s
 
     def filter_pass_debug(self, planes, desc, box=7, colour_in=None, debug=True, allow_nonfinite=False):
-        planes = np.ascontiguousarray(planes, np.float32)
-        assert planes.shape == (NDIM, desc.H, desc.W, desc.S), planes.shape
+        nd, nf, npair, pdt = dims(desc)
+        planes = np.ascontiguousarray(planes, pdt)
+        assert planes.shape == (nd, desc.H, desc.W, desc.S), planes.shape
         H, W, S = desc.H, desc.W, desc.S
         cin = None if colour_in is None else np.ascontiguousarray(colour_in, np.float64)
         out = np.empty((3, H, W, S))
         d, dbg = {}, None
         if debug:
-            d = dict(nbhd_size=np.zeros((H, W), np.int32), mean=np.zeros((H, W, NDIM)), stddev=np.zeros((H, W, NDIM)),
-                     mi=np.zeros((H, W, NPAIR)), alpha=np.zeros((H, W, 3)), beta=np.zeros((H, W, 12)),
-                     wrc=np.zeros((H, W)), bin_hash=np.zeros((H, W, NDIM), np.uint32),
+            d = dict(nbhd_size=np.zeros((H, W), np.int32), mean=np.zeros((H, W, nd)), stddev=np.zeros((H, W, nd)),
+                     mi=np.zeros((H, W, npair)), alpha=np.zeros((H, W, 3)), beta=np.zeros((H, W, nf)),
+                     wrc=np.zeros((H, W)), bin_hash=np.zeros((H, W, nd), np.uint32),
                      member_hash=np.zeros((H, W), np.uint32))
             dbg = Debug(*[_p(d[k]) for k, _ in Debug._fields_])
         st = self._L.rpf_filter_pass_debug(self._h, C.byref(desc), box, _p(planes), _p(cin), _p(out),
@@ -243,6 +266,57 @@ class Context:
     def reduce_device(self, desc, d_colour, d_ray_weight, d_sample_rgb, d_pixel_rgb, stream=None):
         self._check(self._L.rpf_reduce_device(self._h, C.byref(desc), d_colour, d_ray_weight, d_sample_rgb,
                                               d_pixel_rgb, stream))
+
+
+class MultiContext:
+    """rpf_multi: one caller, one row slab per entry of ``devices`` (None = every visible GPU; an ordinal may repeat)"""
+
+    def __init__(self, devices=None):
+        self._L = load()
+        h = C.c_void_p()
+        arr = None if devices is None else (C.c_int32 * len(devices))(*devices)
+        st = self._L.rpf_multi_create(C.byref(h), arr, 0 if devices is None else len(devices))
+        self._h = h
+        if st != OK:
+            msg = self._L.rpf_multi_last_error(h).decode() if h else "no HIP device"
+            if h:
+                self._L.rpf_multi_destroy(h)
+                self._h = None
+            raise RpfError(st, msg)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rpf_multi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def device_count(self):
+        return self._L.rpf_multi_device_count(self._h)
+
+    def counters(self):
+        c = Counters()
+        self._L.rpf_multi_query_counters(self._h, C.byref(c))
+        return c
+
+    def filter(self, planes, desc, ray_weight=None, allow_nonfinite=False):
+        nd, _, _, pdt = dims(desc)
+        planes = np.ascontiguousarray(planes, pdt)
+        assert planes.shape == (nd, desc.H, desc.W, desc.S), planes.shape
+        rw = None if ray_weight is None else np.ascontiguousarray(ray_weight, np.float32)
+        srgb = np.empty((3, desc.H, desc.W, desc.S), np.float32)
+        prgb = np.empty((desc.H, desc.W, 3), np.float32)
+        st = self._L.rpf_multi_filter(self._h, C.byref(desc), _p(planes), _p(rw), _p(srgb), _p(prgb))
+        if st != OK and not (allow_nonfinite and st == E_NONFINITE):
+            raise RpfError(st, self._L.rpf_multi_last_error(self._h).decode())
+        return srgb, prgb, st
 
 
 def lds_bytes_required(S, box):

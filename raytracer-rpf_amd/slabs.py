@@ -64,3 +64,45 @@ def exchange_halo(t, slab, rank, world, group=None):
             req.wait()
     for buf, r0, h in recvs:
         t[:, r0:r0 + h].copy_(buf)  # (host -> device when staged)
+
+
+class HaloPlan:
+    """exchange_halo() with its send / receive staging buffers allocated once (nothing is allocated inside a timed
+    loop): ``plan = HaloPlan(t, slab, rank, world)``, then ``plan.exchange(t)`` before every pass."""
+
+    def __init__(self, t, slab, rank, world, group=None):
+        import torch.distributed as dist
+        self.slab, self.rank, self.world, self.group = slab, rank, world, group
+        self.stage = world > 1 and t.is_cuda and dist.get_backend(group) == "gloo"
+        n_own = slab.row1 - slab.row0
+        assert world == 1 or n_own >= max(slab.halo_top, slab.halo_bottom), "slab thinner than its halo (see slab_for)"
+
+        def buf(h):
+            shape = (t.shape[0], h) + tuple(t.shape[2:])
+            return t.new_empty(shape, device="cpu") if self.stage else t.new_empty(shape)
+
+        self.up = (buf(slab.halo_top), buf(slab.halo_top)) if world > 1 and rank > 0 and slab.halo_top > 0 else None
+        self.dn = (buf(slab.halo_bottom), buf(slab.halo_bottom)) if world > 1 and rank < world - 1 and slab.halo_bottom > 0 else None
+
+    def exchange(self, t):
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        slab, rank, group = self.slab, self.rank, self.group
+        n_own, top0 = slab.row1 - slab.row0, slab.halo_top
+        ops = []
+        if self.up is not None:
+            h = slab.halo_top
+            self.up[0].copy_(t[:, top0:top0 + h])                       # my first h owned rows -> bottom halo of rank-1
+            ops += [dist.P2POp(dist.isend, self.up[0], rank - 1, group), dist.P2POp(dist.irecv, self.up[1], rank - 1, group)]
+        if self.dn is not None:
+            h = slab.halo_bottom
+            self.dn[0].copy_(t[:, top0 + n_own - h:top0 + n_own])       # my last h owned rows -> top halo of rank+1
+            ops += [dist.P2POp(dist.isend, self.dn[0], rank + 1, group), dist.P2POp(dist.irecv, self.dn[1], rank + 1, group)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if self.up is not None:
+            t[:, 0:slab.halo_top].copy_(self.up[1])
+        if self.dn is not None:
+            t[:, top0 + n_own:top0 + n_own + slab.halo_bottom].copy_(self.dn[1])

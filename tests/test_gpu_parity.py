@@ -417,6 +417,171 @@ def test_degenerate_cells_take_the_full_table_path(ctx, hipmod, oracle):
     check_pass(got, want)
 
 
+# ---- BASELINE configs[4]: 27-dim sample vectors (4 random parameters, 18 features), fp16 feature storage -------------
+L27 = dict(n_random=4, n_feat=18)
+
+
+def planes27(W, H, S, **kw):
+    """fp16-stored 27-dim buffer and its exact fp32 image (what the oracle reads)"""
+    p16 = fb.synth_planes(W, H, S, dtype="f16", **L27, **kw)
+    return p16, p16.astype(np.float32)
+
+
+@pytest.mark.parametrize("W,H,S,box,mode,sf,sc,policy", [
+    (14, 10, 8, 7, "clustered", 1e-3, 0.01, 1),
+    (14, 10, 8, 7, "smooth", 0.05, 1e-4, 0),     # REF_ABORT on a buffer the reference algebra completes
+    (12, 8, 16, 7, "smooth", 0.05, 1e-4, 1),     # K = 13
+    (10, 8, 4, 5, "clustered", 1e-3, 0.01, 1),
+    (9, 7, 32, 7, "smooth", 0.05, 1e-4, 1),      # four waves per pixel
+    (8, 6, 64, 7, "smooth", 0.05, 1e-4, 1),      # the 64 spp kernel of configs[4]
+    (7, 5, 1, 7, "smooth", 0.05, 1e-4, 1),
+    (30, 12, 8, 7, "smooth", 2e-3, 0.01, 1),     # small neighbourhoods
+])
+def test_layout27_fp16_filter_pass_vs_oracle(ctx, hipmod, oracle, W, H, S, box, mode, sf, sc, policy):
+    """every stage output of the 27-dim / fp16-storage kernels against the oracle run on the same values: 180 MI pairs
+    (18 x 6 feature pairs + 3 x 24 colour pairs, rpf.cpp:416-442 with the loop bounds generalised), 23 weighted columns"""
+    p16, p32 = planes27(W, H, S, seed=19, sigma_f=sf, sigma_c=sc, mode=mode)
+    got = ctx.filter_pass_debug(p16, hipmod.make_desc(W, H, S, policy=policy, plane_dtype=hipmod.PLANES_F16, **L27), box=box,
+                                allow_nonfinite=True)
+    want = oracle.filter_pass(p32, oracle.make_desc(W, H, S, box=box, policy=policy, **L27))
+    assert got["mi"].shape[-1] == 180 and got["beta"].shape[-1] == 18 and got["mean"].shape[-1] == 27
+    assert got["nonfinite_pixels"] == want["nonfinite_pixels"]
+    if np.isfinite(want["colour"]).all():
+        check_pass(got, want)
+    else:
+        for k in ("nbhd_size", "member_hash", "bin_hash"):
+            assert (got[k] == want[k]).all()
+        assert (np.isfinite(got["colour"]) == np.isfinite(want["colour"])).all()
+
+
+@pytest.mark.parametrize("beta_map", [0, 1, 2])
+def test_layout27_beta_presets_and_activity(ctx, hipmod, oracle, beta_map):
+    W, H, S = 16, 12, 8
+    p16, p32 = planes27(W, H, S, seed=2, sigma_f=1e-3, sigma_c=0.01, mode="clustered")
+    got = ctx.filter_pass_debug(p16, hipmod.make_desc(W, H, S, beta_map=beta_map, policy=1, plane_dtype=hipmod.PLANES_F16, **L27), box=7)
+    want = oracle.filter_pass(p32, oracle.make_desc(W, H, S, box=7, beta_map=beta_map, policy=1, **L27))
+    check_pass(got, want)
+    assert rel_l2(want["colour"], p32[2:5].astype(np.float64)) > 1e-3   # not the identity
+
+
+def test_layout27_multi_pass_host_entry_and_stage1a(ctx, hipmod, oracle):
+    W, H, S = 15, 11, 8
+    p16, p32 = planes27(W, H, S, seed=5, sigma_f=1e-3, sigma_c=0.01, mode="clustered")
+    d = hipmod.make_desc(W, H, S, boxes=(7, 5), policy=1, plane_dtype=hipmod.PLANES_F16, **L27)
+    m, sd = ctx.pixel_stats(p16, d)
+    mo, so = oracle.pixel_stats(p32, oracle.make_desc(W, H, S, **L27))
+    assert m.shape[-1] == 18 and np.array_equal(m, mo) and np.array_equal(sd, so, equal_nan=True)
+    srgb, prgb, st, c64 = ctx.filter(p16, d, want_colour64=True)
+    assert st == hipmod.OK
+    c = None
+    for box in (7, 5):
+        c = oracle.filter_pass(p32, oracle.make_desc(W, H, S, box=box, policy=1, **L27), colour_in=c, debug=False)["colour"]
+    assert rel_l2(c64, c) <= 1e-9
+    # the pinned-buffer band pipeline moves fp16 planes too
+    pin = ctx.host_empty(p16.shape, np.float16)
+    pin[...] = p16
+    out_s, out_p = ctx.host_empty(srgb.shape), ctx.host_empty(prgb.shape)
+    ctx.filter(pin, d, out_samples=out_s, out_pixels=out_p)
+    assert np.array_equal(out_s, srgb) and np.array_equal(out_p, prgb)
+
+
+def test_layout_rejections(ctx, hipmod):
+    planes = np.zeros((27, 4, 4, 2), np.float32)
+    with pytest.raises(hipmod.RpfError) as e:   # 27 dims exist with fp16 planes only
+        ctx.filter(planes, hipmod.make_desc(4, 4, 2, **L27))
+    assert e.value.status == hipmod.E_UNSUPPORTED
+    with pytest.raises(hipmod.RpfError) as e:
+        ctx.filter(np.zeros((25, 4, 4, 2), np.float16), hipmod.make_desc(4, 4, 2, n_random=2, n_feat=18, plane_dtype=hipmod.PLANES_F16))
+    assert e.value.status == hipmod.E_UNSUPPORTED
+
+
+def test_config5_shape_slab_8192x70x64_fp16(ctx, hipmod, oracle):
+    """BASELINE configs[4]: 8192 x 8192 x 64 spp, 27 dims, fp16 storage (232 GB of features: a slab at a time, generated
+    on the device in row chunks).  One slab of 64 owned rows + 3 halo rows either side: determinism, neighbourhood
+    bounds, hull bounds, and the oracle on a 512-pixel-wide cut of one owned row."""
+    import torch
+    W, S, b, own = 8192, 64, 3, 64
+    H = own + 2 * b
+    dev = torch.device("cuda", 0)
+    planes = fb.synth_planes_chunked(W, H, S, rows_per_chunk=8, row0=4000, xp=fb.torch_backend(dev), mode="smooth",
+                                     sigma_f=0.05, sigma_c=1e-4, dtype="f16", **L27).contiguous()
+    assert planes.dtype == torch.float16 and planes.shape == (27, H, W, S)
+    desc = hipmod.make_desc(W, H, S, row_begin=b, row_end=b + own, policy=hipmod.DEGEN_EPS, plane_dtype=hipmod.PLANES_F16, **L27)
+    stream = torch.cuda.current_stream().cuda_stream
+    col0 = torch.empty((3, H, W, S), dtype=torch.float64, device=dev)
+    ctx.colour_from_planes_device(desc, planes.data_ptr(), col0.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.equal(col0, planes[2:5].to(torch.float64))
+    outs = []
+    for _ in range(2):
+        c = col0.clone()
+        ctx.filter_device(desc, planes.data_ptr(), c.data_ptr(), stream)
+        outs.append(c)
+    torch.cuda.synchronize()
+    out = outs[0]
+    assert torch.equal(out, outs[1])
+    cnt = ctx.counters()
+    assert cnt.samples_filtered == own * W * S and cnt.nonfinite_pixels == 0 and S <= cnt.max_nbhd <= 49 * S
+    pad = torch.nn.functional.pad
+    cmin, cmax = col0.amin(dim=3), col0.amax(dim=3)
+    wmin = -torch.nn.functional.max_pool2d(pad(-cmin, (b, b, b, b), value=-1e30), 2 * b + 1, stride=1)
+    wmax = torch.nn.functional.max_pool2d(pad(cmax, (b, b, b, b), value=-1e30), 2 * b + 1, stride=1)
+    assert bool((out >= wmin[..., None] - 1e-9).all()) and bool((out <= wmax[..., None] + 1e-9).all())
+    r0, x0, xw = 30, 3000, 512
+    host = planes[:, r0 - b:r0 + 1 + b, x0 - b:x0 + xw + b].float().cpu().numpy()
+    want = oracle.filter_pass(host, oracle.make_desc(xw + 2 * b, 2 * b + 1, S, box=7, row_begin=b, row_end=b + 1,
+                                                     policy=oracle.DEGEN_EPS, **L27), debug=False)["colour"][:, b:b + 1, b:b + xw]
+    assert rel_l2(out[:, r0:r0 + 1, x0:x0 + xw].cpu().numpy(), want) <= REL_L2_BAR
+
+
+@pytest.mark.parametrize("devices,boxes,S", [((0, 0), (7, 5), 8), ((0, 0, 0), (7, 7, 5), 8), ((0, 0), (7,), 16), ((0,), (7, 5), 8)])
+def test_multi_context_row_slabs_equal_one_context(ctx, hipmod, oracle, devices, boxes, S):
+    """rpf_multi_filter: one caller, one row slab per device entry, colour halo refreshed between passes by device-to-
+    device (peer) copies of the neighbours' owned rows.  Rehearsed on the one GPU of this box with several slab contexts
+    on device 0: filtered samples, pixel means and merged counters must equal the single-context full-frame call bit for
+    bit (the reference filters the whole film every pass, rpf.cpp:732)."""
+    W, H = 21, 37
+    planes = fb.synth_planes(W, H, S, seed=3, sigma_f=1e-3, sigma_c=0.01, mode="clustered")
+    rw = (0.5 + np.random.default_rng(4).random((H, W, S))).astype(np.float32)
+    desc = hipmod.make_desc(W, H, S, boxes=boxes, policy=hipmod.DEGEN_EPS)
+    s1, p1, st = ctx.filter(planes, desc, ray_weight=rw)
+    c1 = ctx.counters()
+    with hipmod.MultiContext(list(devices)) as mc:
+        assert mc.device_count == len(devices)
+        s2, p2, st2 = mc.filter(planes, desc, ray_weight=rw)
+        c2 = mc.counters()
+    assert st == st2 == hipmod.OK
+    assert np.array_equal(s1, s2) and np.array_equal(p1, p2)
+    assert (c2.samples_filtered, c2.sum_nbhd, c2.max_nbhd, c2.nonfinite_pixels) == (
+        c1.samples_filtered, c1.sum_nbhd, c1.max_nbhd, c1.nonfinite_pixels)
+    # and the oracle's multi-pass chain on the whole film
+    c = None
+    for box in boxes:
+        c = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=box, policy=1), colour_in=c, debug=False)["colour"]
+    assert rel_l2(s2.astype(np.float64), c) <= REL_L2_BAR
+
+
+def test_multi_context_errors_and_nonfinite_pixel(hipmod, oracle):
+    W, H, S = 12, 16, 8
+    planes = fb.synth_planes(W, H, S, seed=5)
+    planes[7:10] = np.float32([0.0, 0.0, 1.0])[:, None, None, None]   # constant normal: 0/0 under REF_ABORT (SURVEY F2)
+    want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7))
+    with hipmod.MultiContext([0, 0]) as mc:
+        srgb, prgb, st = mc.filter(planes, hipmod.make_desc(W, H, S), allow_nonfinite=True)
+        assert st == hipmod.E_NONFINITE
+        c = mc.counters()
+        assert c.nonfinite_pixels == want["nonfinite_pixels"] and c.first_bad_pixel == want["first_bad_pixel"]
+        with pytest.raises(hipmod.RpfError) as e:      # a slab thinner than its neighbours' halo
+            mc.filter(planes[:, :4], hipmod.make_desc(W, 4, S, boxes=(7,)))
+        assert e.value.status == hipmod.E_BADARG
+        with pytest.raises(hipmod.RpfError) as e:      # the slabs are rpf_multi's own
+            mc.filter(planes, hipmod.make_desc(W, H, S, row_begin=2, row_end=10))
+        assert e.value.status == hipmod.E_BADARG
+    with pytest.raises(hipmod.RpfError) as e:
+        hipmod.MultiContext([0, 99])
+    assert e.value.status == hipmod.E_BADARG
+
+
 def test_multi_pass_on_a_sub_slab_is_refused(ctx, hipmod):
     """the reference filters the whole film every pass (rpf.cpp:732); a strict sub-slab with n_box > 1 would read
     unfiltered halo colours in pass 2, so the ABI refuses it (one pass per call + halo exchange, or rpf_filter_multi)"""

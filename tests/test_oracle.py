@@ -174,6 +174,31 @@ def test_oracle_reproduces_committed_end_to_end_fixtures(oracle, name):
     assert r["status"] == int(g["status"])
 
 
+def test_oracle_generalised_layout(oracle):
+    """the oracle's loops take the column-group sizes from the descriptor: with (2, 12) they are the reference's (every
+    pin above runs through them); with (4, 18) the pair order is rpf.cpp:416-442's with the bounds widened"""
+    a, b = oracle.pair_table(4, 18)
+    assert len(a) == 18 * 6 + 3 * 24 == 180
+    assert list(a[:6]) == [9] * 6 and list(b[:6]) == [5, 6, 7, 8, 0, 1]          # f0 x (r0..r3, p0, p1)
+    assert list(a[108:114]) == [2] * 6 and list(b[108:114]) == [5, 6, 7, 8, 0, 1] and list(b[114:132]) == list(range(9, 27))
+    a19, b19 = oracle.pair_table()
+    a2, b2 = oracle.pair_table(2, 12)
+    assert np.array_equal(a19, a2) and np.array_equal(b19, b2)
+    # a 27-dim buffer whose extra columns are copies: the shared statistics equal the 19-dim run's
+    from raytracer_rpf_amd import feature_buffer as fb
+    W, H, S = 9, 7, 8
+    p19 = fb.synth_planes(W, H, S, seed=4, sigma_f=1e-3, sigma_c=0.01, mode="clustered")
+    p27 = fb.synth_planes(W, H, S, seed=4, sigma_f=1e-3, sigma_c=0.01, mode="clustered", n_random=4, n_feat=18)
+    assert np.array_equal(p27[:7], p19[:7]) and np.array_equal(p27[9:21], p19[7:19])
+    r19 = oracle.filter_pass(p19, oracle.make_desc(W, H, S, policy=1))
+    r27 = oracle.filter_pass(p27, oracle.make_desc(W, H, S, policy=1, n_random=4, n_feat=18))
+    assert r27["mi"].shape[-1] == 180 and r27["beta"].shape[-1] == 18
+    same = r19["nbhd_size"] == r27["nbhd_size"]     # six more features can only reject more neighbours
+    assert (r27["nbhd_size"] <= r19["nbhd_size"]).all() and same.any()
+    assert np.array_equal(r27["mean"][same][:, :7], r19["mean"][same][:, :7])
+    assert np.array_equal(r27["mean"][same][:, 9:21], r19["mean"][same][:, 7:19])
+
+
 def test_oracle_invariants(oracle):
     """Appendix-A invariants: own samples are the first S members so w_ii = 1; non-colour columns are never
     written; thread count does not change results; pair table is the ComputeCFWeights call order."""
