@@ -60,6 +60,9 @@ def build(force=False, verbose=False):
             raise RuntimeError("miscompiled spill placement in the kernel TU (see scripts/check_spills.py):\n" + chk.stdout)
         if verbose:
             print(chk.stdout)
+    for f in glob.glob(os.path.join(OBJ_DIR, "*")):  # the -save-temps intermediates (~100 MB) have served their purpose
+        if f not in objs:
+            os.remove(f)
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))

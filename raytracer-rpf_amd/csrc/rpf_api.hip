@@ -39,11 +39,13 @@ struct rpf_ctx {
     uint32_t *d_lists = nullptr; size_t cap_lists = 0;     // size binning: [7][H*W] pixel lists
     uint32_t *d_class_counts = nullptr;                    // [7]
     uint64_t *d_masks = nullptr; size_t cap_masks = 0;     // size binning: stage-1b acceptance masks [H*W][stride]
+    char *d_big_list = nullptr;  size_t cap_big_list = 0;  // streaming kernel: member lists [slots][nmax] u32
+    char *d_big_bins = nullptr;  size_t cap_big_bins = 0;  //                   bin ids [slots][ndim][nmax] u8
     // membership depends on the features only, so within one call a pass with the same box and rows re-uses the
     // previous pass's masks and lists (reset at every API entry: the planes may change between calls)
     bool bin_valid = false;
     int bin_box = 0, bin_r0 = 0, bin_r1 = 0;
-    uint32_t bin_counts[kNumClasses] = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t bin_counts[kNumClasses] = {0, 0, 0, 0, 0, 0, 0, 0};
     // debug planes
     void *d_dbg[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_dbg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -158,8 +160,14 @@ int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const void *d_plane
     p.fast_weights = (d->flags & RPF_FLAG_FAST_WEIGHTS) ? 1 : 0;
     p.stage_mask = ctx->tun.stage_mask; // timing ablation knob (rpf_set_option); results are wrong unless -1
     const int64_t nmax64 = (int64_t)box * box * d->S;
-    if (nmax64 > 49 * 64) return fail(ctx, RPF_E_UNSUPPORTED, "box*box*S > 3136: neighbourhood too large for the LDS-resident kernels");
+    if (nmax64 > kMaxNbhd) return fail(ctx, RPF_E_UNSUPPORTED, "box*box*S > 65535: neighbourhood too large (16-bit histogram cells, one-byte bin ids)");
     p.nmax = (int)nmax64;
+    {   // XCD strip width: box rows x (strip + halo) px x S samples x ~88 B should use about a quarter of the 4 MiB L2
+        const int64_t per_px = (int64_t)box * d->S * 88;
+        int w = (int)((1 << 20) / std::max<int64_t>(per_px, 1)) - 2 * ((box - 1) / 2);
+        w = std::max(8, std::min(128, w));
+        p.strip_w = w & ~7;
+    }
     p.bmax = (int)std::sqrt((double)p.nmax);
     if (p.bmax < 1) p.bmax = 1;
     p.eps = d->eps; p.seed = d->sigma_seed;
@@ -175,7 +183,10 @@ int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const void *d_plane
     p.pmean = ctx->d_pmean; p.pstd = ctx->d_pstd; p.tfix = ctx->d_tfix; p.dfix = ctx->d_dfix;
     p.nbhd = ctx->d_nbhd; p.status = ctx->d_status;
     if (dbg_dev) p.dbg = *dbg_dev;
-    out.lds = lds_layout(p.S, p.nmax, p.bmax, table_in_lds(p.S, p.nmax, p.bmax, ctx->tun, p.lay), ctx->tun, p.lay).total;
+    {   // LDS of the largest resident kernel this pass can launch (larger neighbourhoods stream: filter_pixel_big_kernel)
+        const int nres = std::min(p.nmax, kMaxResident), bres = std::max(1, (int)std::sqrt((double)nres));
+        out.lds = lds_layout(p.S, nres, bres, table_in_lds(p.S, nres, bres, ctx->tun, p.lay), ctx->tun, p.lay).total;
+    }
     if ((int)out.lds > max_lds_per_block())
         return fail(ctx, RPF_E_UNSUPPORTED, "neighbourhood working set exceeds 160 KiB of LDS");
     return RPF_OK;
@@ -190,6 +201,7 @@ int32_t finish_counters(rpf_ctx *ctx, const rpf_desc *d, hipStream_t s);
 int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p, hipStream_t s, int *launches) {
     bool bin = p.nmax > 512;
     if (ctx->tun.binning >= 0) bin = ctx->tun.binning != 0;
+    if (p.nmax > kMaxResident) bin = true; // the streaming kernel takes the pixels no resident kernel can hold
     if (p.dbg.nbhd_size || p.dbg.mi) { /* debug planes are written by whichever launch owns the pixel: fine */ }
     if (!bin) {
         HIP_TRY(launch_filter_pass(p, ctx->tun, s, nullptr));
@@ -219,6 +231,10 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p, hipStream_t s, i
         ctx->bin_box = p.box; ctx->bin_r0 = p.row_begin; ctx->bin_r1 = p.row_end;
         ctx->bin_valid = true;
     }
+    // the four-wave kernels keep one acceptance mask per 64 candidates of the WINDOW in a 64-entry LDS array: windows
+    // beyond 4096 candidates (boxes 17 and up) run their resident classes on the one-wave instantiations
+    Tuning tun = ctx->tun;
+    if ((int64_t)(p.box * p.box - 1) * p.S > 4096) tun.waves_per_pixel = 1;
     for (int c = 0; c < kNumClasses; ++c) {
         if (counts[c] == 0) continue;
         PassParams q = pc;
@@ -226,7 +242,14 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p, hipStream_t s, i
         q.bmax = std::max(1, (int)std::sqrt((double)q.nmax));
         q.pix_list = ctx->d_lists + (size_t)c * HW;
         q.list_count = counts[c];
-        HIP_TRY(launch_filter_pass(q, ctx->tun, s, nullptr));
+        if (c == kNumClasses - 1) { // neighbourhoods beyond the LDS-resident kernels: stream through global scratch
+            const uint32_t slots = std::min<uint32_t>(counts[c], 1024u);
+            if ((st = ensure(ctx, ctx->d_big_list, ctx->cap_big_list, (size_t)slots * q.nmax * 4))) return st;
+            if ((st = ensure(ctx, ctx->d_big_bins, ctx->cap_big_bins, (size_t)slots * q.nmax * p.lay.ndim()))) return st;
+            HIP_TRY(launch_filter_big(q, ctx->d_big_list, ctx->d_big_bins, slots, s));
+        } else {
+            HIP_TRY(launch_filter_pass(q, tun, s, nullptr));
+        }
         if (launches) ++*launches;
     }
     return RPF_OK;
@@ -488,7 +511,7 @@ void rpf_destroy(rpf_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *bufs[] = {ctx->d_planes, ctx->d_rayw, ctx->d_colA, ctx->d_colB, ctx->d_pmean, ctx->d_pstd, ctx->d_nbhd,
                     ctx->d_tfix, ctx->d_dfix, ctx->d_srgb, ctx->d_prgb, ctx->d_status, ctx->d_nred, ctx->d_lists,
-                    ctx->d_class_counts, ctx->d_masks};
+                    ctx->d_class_counts, ctx->d_masks, ctx->d_big_list, ctx->d_big_bins};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (void *b : ctx->d_dbg)

@@ -32,6 +32,7 @@ struct PassParams {
     int32_t beta_map, policy;
     int32_t fast_weights;  // RPF_FLAG_FAST_WEIGHTS: fp32 pair arithmetic in stage 4
     int32_t stage_mask;    // diagnostics only (rpf_set_option "stage_mask"): bit0 stats chain, bit1 bins, bit2 MI, bit3 weights; -1 = all
+    int32_t strip_w;       // pixels per XCD strip of the pixel walk (slab_pixel)
     int32_t nmax;          // box*box*S: capacity of a neighbourhood
     int32_t bmax;          // floor(sqrt(nmax)): max histogram bins per axis
     double eps, seed, sigma_p;
@@ -79,9 +80,14 @@ hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s);
 hipError_t launch_pixel_stats_rows(const PassParams &p, int r0, int r1, hipStream_t s);
 hipError_t launch_filter_pass(const PassParams &p, const Tuning &tun, hipStream_t s, uint32_t *lds_bytes_out);
 // neighbourhood-size binning (large box*box*S): count N per pixel, then deal the pixels into one list per kernel family
-constexpr int kNumClasses = 7;
-int class_capacity(int c);          // 64, 128, 256, 448, 832, 1600, 3136
+constexpr int kNumClasses = 8;      // seven LDS-resident kernel families + the streaming kernel for larger neighbourhoods
+constexpr int kMaxResident = 3136;  // largest neighbourhood the LDS-resident kernels hold (64 lanes x 49 samples)
+constexpr int kMaxNbhd = 65535;     // the streaming kernel: 16-bit histogram cells, one-byte bin ids
+int class_capacity(int c);          // 64, 128, 256, 448, 832, 1600, 3136, 65535
 hipError_t launch_nbhd_count(const PassParams &p, hipStream_t s);
+// the streaming kernel (neighbourhoods of the last size class): global scratch of `slots` workgroups,
+// list [slots][nmax] u32 and bins [slots][ndim][nmax] u8
+hipError_t launch_filter_big(const PassParams &p, void *list, void *bins, uint32_t slots, hipStream_t s);
 hipError_t launch_classify(const PassParams &p, uint32_t *lists /*[7][H*W]*/, uint32_t *counts /*[7], zeroed*/, hipStream_t s);
 hipError_t launch_colour_from_planes(const void *planes, bool f16, double *colour, uint64_t plane_stride, hipStream_t s);
 hipError_t launch_colour_from_planes_span(const void *planes, bool f16, double *colour, uint64_t plane_stride, uint64_t e0,

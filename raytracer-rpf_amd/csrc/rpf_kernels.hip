@@ -228,11 +228,13 @@ __device__ __forceinline__ uint32_t div_magic(uint32_t d) { return 0xFFFFFFFFu /
 __device__ __forceinline__ uint32_t div_small(uint32_t n, uint32_t M) { return M ? __umulhi(n, M) : n; } // M == 0: d == 1
 
 // XCD- and L2-aware pixel order of a slab.  Blocks with equal (blockIdx % 8) share an XCD and its 4 MiB L2: XCD r
-// filters one contiguous band of rows, and walks it in vertical strips of kStripW pixels (row by row inside a strip),
-// so the 7-row window data of the ~256 pixels in flight on the XCD (and the 6 rows shared with the next strip row)
-// stay L2-resident instead of being re-fetched once per image row.  (r, ql) -> pixel; false = no such pixel.
+// filters one contiguous band of rows, and walks it in vertical strips of p.strip_w pixels (row by row inside a strip),
+// so the box-row window data of the pixels in flight on the XCD (and the rows shared with the next strip row) stay
+// L2-resident instead of being re-fetched once per image row.  The strip width is set by the host so that `box` rows of
+// a strip (+ halo columns) at ~88 B per sample stay well inside the L2: 128 px at 8 spp, 32 px at 32 spp (a 128-px strip
+// at 32 spp fetched 7.8x the compulsory bytes).  (r, ql) -> pixel; false = no such pixel.
 __device__ __forceinline__ bool slab_pixel(const PassParams &p, int r, int64_t ql, int &x, int &y) {
-    constexpr int kStripW = 128;
+    const uint32_t kStripW = (uint32_t)p.strip_w;
     const int W = p.W;
     const int rows_own = p.row_end - p.row_begin;
     const int rows_band = (rows_own + 7) / 8;
@@ -242,7 +244,7 @@ __device__ __forceinline__ bool slab_pixel(const PassParams &p, int r, int64_t q
     if (ql >= (int64_t)band_rows * W) return false;
     const uint32_t q = (uint32_t)ql;                       // band_rows * W < 2^32 (host-checked: W*H*S < 2^32)
     const uint32_t full_strips = (uint32_t)W / kStripW;
-    const uint32_t strip_px = (uint32_t)kStripW * (uint32_t)band_rows;
+    const uint32_t strip_px = kStripW * (uint32_t)band_rows;
     int yl;
     if (q < full_strips * strip_px) {
         const uint32_t sidx = q / strip_px;
@@ -533,7 +535,7 @@ hipError_t launch_filter_pass(const PassParams &p, const Tuning &tun, hipStream_
 }
 
 int class_capacity(int c) {
-    static const int caps[kNumClasses] = {64, 128, 256, 448, 832, 1600, 3136}; // 64 * {1, 2, 4, 7, 13, 25, 49}
+    static const int caps[kNumClasses] = {64, 128, 256, 448, 832, 1600, 3136, kMaxNbhd}; // 64 * {1, 2, 4, 7, 13, 25, 49}, streaming
     return caps[c];
 }
 
@@ -542,6 +544,11 @@ hipError_t launch_nbhd_count(const PassParams &p, hipStream_t s) {
     if (npix <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((npix + 3) / 4);
     return p.lay.is_ref19() ? d19::impl_nbhd_count(p, grid, s) : d27::impl_nbhd_count(p, grid, s);
+}
+
+hipError_t launch_filter_big(const PassParams &p, void *list, void *bins, uint32_t slots, hipStream_t s) {
+    if (!p.lay.supported() || p.masks == nullptr || p.pix_list == nullptr) return hipErrorInvalidValue;
+    return p.lay.is_ref19() ? d19::impl_filter_big(p, list, bins, slots, s) : d27::impl_filter_big(p, list, bins, slots, s);
 }
 
 hipError_t launch_classify(const PassParams &p, uint32_t *lists, uint32_t *counts, hipStream_t s) {

@@ -582,6 +582,36 @@ def test_multi_context_errors_and_nonfinite_pixel(hipmod, oracle):
     assert e.value.status == hipmod.E_BADARG
 
 
+@pytest.mark.parametrize("W,H,S,box,mode,sf,sc", [
+    (22, 19, 16, 17, "smooth", 0.05, 1e-4),     # box 17 x 16 spp: N up to 4624 (> 3136: the streaming kernel)
+    (38, 36, 8, 35, "smooth", 0.05, 1e-4),      # box 35 x 8 spp: N up to 9800
+    (26, 21, 8, 17, "clustered", 1e-3, 0.01),   # box 17, small / mid neighbourhoods: resident classes under a large window
+    (13, 11, 8, 55, "smooth", 0.05, 1e-4),      # box 55 on a frame smaller than the box: every window is the whole frame
+])
+def test_large_boxes_vs_oracle(ctx, hipmod, oracle, W, H, S, box, mode, sf, sc):
+    """the reference's commented box list {55, 35, 17, 7} (rpf.cpp:767): neighbourhoods beyond 3136 samples stream
+    their member list and bin ids through global scratch (filter_pixel_big_kernel); pixels of the same pass whose N is
+    small still run the LDS-resident kernels.  Every stage output against the oracle."""
+    planes = fb.synth_planes(W, H, S, seed=29, sigma_f=sf, sigma_c=sc, mode=mode)
+    got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS), box=box)
+    want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=box, policy=oracle.DEGEN_EPS))
+    check_pass(got, want)
+    if box in (17, 35) and mode == "smooth":
+        assert want["nbhd_size"].max() > 3136      # the streaming kernel ran
+
+
+def test_large_box_list_17_7_at_16spp(ctx, hipmod, oracle):
+    """the multi-pass entry with a box list that mixes the streaming kernel ({17} at 16 spp) and the resident ones"""
+    W, H, S = 21, 20, 16
+    planes = fb.synth_planes(W, H, S, seed=30, sigma_f=0.05, sigma_c=1e-4, mode="smooth")
+    srgb, prgb, st, c64 = ctx.filter(planes, hipmod.make_desc(W, H, S, boxes=(17, 7), policy=hipmod.DEGEN_EPS), want_colour64=True)
+    assert st == hipmod.OK
+    c = None
+    for box in (17, 7):
+        c = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=box, policy=1), colour_in=c, debug=False)["colour"]
+    assert rel_l2(c64, c) <= 1e-9
+
+
 def test_multi_pass_on_a_sub_slab_is_refused(ctx, hipmod):
     """the reference filters the whole film every pass (rpf.cpp:732); a strict sub-slab with n_box > 1 would read
     unfiltered halo colours in pass 2, so the ABI refuses it (one pass per call + halo exchange, or rpf_filter_multi)"""
@@ -597,8 +627,8 @@ def test_badarg_and_unsupported(ctx, hipmod):
     with pytest.raises(hipmod.RpfError) as e:
         ctx.filter(planes, hipmod.make_desc(4, 4, 2, boxes=(4,)))
     assert e.value.status == hipmod.E_BADARG
-    with pytest.raises(hipmod.RpfError) as e:
-        ctx.filter(planes, hipmod.make_desc(4, 4, 2, boxes=(55,)))
+    with pytest.raises(hipmod.RpfError) as e:   # box*box*S = 96800 > 65535: beyond the streaming kernel's 16-bit cells
+        ctx.filter(np.zeros((19, 4, 4, 32), np.float32), hipmod.make_desc(4, 4, 32, boxes=(55,)))
     assert e.value.status == hipmod.E_UNSUPPORTED
 
 
