@@ -272,6 +272,20 @@ def main():
             out["fast_weights_f32"] = {"kernel_ms": min(ms), "Msamples_per_s_kernel": n_own * W * S / (min(ms) * 1e-3) / 1e6,
                                        "rel_l2_vs_f64_path": rel}
 
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not layout:
+        # the headline buffer is the near-identity regime (every cross weight underflows), so its GPU-vs-oracle
+        # figure says little about stage 4: the same comparison on a small filter-ACTIVE buffer (clustered generator)
+        import numpy as np
+        import pyoracle as O
+        Wp, Hp, Sp = 256, 48, 8
+        pl = fb.synth_planes(Wp, Hp, Sp, seed=11, sigma_f=1e-3, sigma_c=0.01, mode="clustered")
+        got = ctx.filter_pass_debug(pl, hip.make_desc(Wp, Hp, Sp), box=box, debug=False)["colour"]
+        want = O.filter_pass(pl, O.make_desc(Wp, Hp, Sp, box=box), debug=False)["colour"]
+        cin = pl[2:5].astype(np.float64)
+        out["parity_probe"] = {"buffer": "clustered %dx%dx%d, sigma_f=1e-3 (filter-active)" % (Wp, Hp, Sp),
+                               "activity_rel_l2": float(np.linalg.norm(want - cin) / np.linalg.norm(cin)),
+                               "gpu_vs_oracle_rel_l2": float(np.linalg.norm(got - want) / np.linalg.norm(want))}
+
     # ---- strong scaling of BASELINE configs[3]: 3840x2160x32 spp row-tiled over the N ranks ---------------------------
     if args.workload == "cfg2" and not args.no_scaling_4k32 and not args.option:
         del job

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep: random frame shapes, sample counts, box sizes, generator modes, policies and beta presets
 through rpf_filter_pass_debug vs the CPU oracle, with the bars of tests/test_gpu_parity.py (bit-exact membership /
-order / bins / statistics, MI 1e-11, alpha/beta/W 1e-9 (EPS-degenerate: 5e-3), RGB 1e-4 rel-L2).  usage: fuzz_parity.py [cases] [seed]"""
+order / bins / statistics, MI 1e-11, alpha/beta/W 1e-9 under both policies, RGB 1e-4 rel-L2).  Round 2: both sample
+layouts (19-dim fp32, 27-dim fp16), boxes up to 21 (neighbourhoods beyond 3136 samples run the streaming kernel).
+usage: fuzz_parity.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -18,11 +20,13 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2025)
 ctx = hip.Context(0)
 fails = 0
 for i in range(cases):
-    box = int(rng.choice([3, 5, 7, 7, 7, 9, 11]))
-    smax = max(1, 3136 // (box * box))
+    box = int(rng.choice([3, 5, 7, 7, 7, 9, 11, 13, 17, 21]))
+    wide = bool(rng.integers(0, 4) == 0)   # one case in four: the 27-dim fp16 layout
+    L = dict(n_random=4, n_feat=18) if wide else {}
+    smax = max(1, 65535 // (box * box))
     S = int(rng.choice([s for s in (1, 2, 3, 4, 5, 8, 8, 12, 16, 24, 32, 48, 64) if s <= smax]))
     W, H = int(rng.integers(3, 26)), int(rng.integers(2, 18))
-    while W * H * S > 60000:  # keep the oracle in seconds
+    while W * H * S > (30000 if box > 11 or wide else 60000):  # keep the oracle in seconds
         W, H = max(3, W - 2), max(2, H - 1)
     mode = str(rng.choice(["smooth", "clustered"]))
     sf = float(rng.choice([1e-5, 1e-3, 0.02, 0.05]))
@@ -31,9 +35,11 @@ for i in range(cases):
     seed = int(rng.integers(0, 1 << 30))
     if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != i:
         continue
-    planes = fb.synth_planes(W, H, S, seed=seed, sigma_f=sf, sigma_c=0.01, mode=mode)
-    got = ctx.filter_pass_debug(planes, hip.make_desc(W, H, S, policy=policy, beta_map=beta), box=box, allow_nonfinite=True)
-    want = O.filter_pass(planes, O.make_desc(W, H, S, box=box, policy=policy, beta_map=beta))
+    planes = fb.synth_planes(W, H, S, seed=seed, sigma_f=sf, sigma_c=0.01, mode=mode, dtype="f16" if wide else "f32", **L)
+    got = ctx.filter_pass_debug(planes, hip.make_desc(W, H, S, policy=policy, beta_map=beta,
+                                                      plane_dtype=hip.PLANES_F16 if wide else hip.PLANES_F32, **L),
+                                box=box, allow_nonfinite=True)
+    want = O.filter_pass(planes.astype(np.float32), O.make_desc(W, H, S, box=box, policy=policy, beta_map=beta, **L))
     ok, why = True, ""
     try:
         for k in ("nbhd_size", "member_hash", "bin_hash"):
@@ -41,7 +47,7 @@ for i in range(cases):
         assert np.array_equal(got["mean"], want["mean"], equal_nan=True), "mean"
         assert np.array_equal(got["stddev"], want["stddev"], equal_nan=True), "stddev"
         np.testing.assert_allclose(got["mi"], want["mi"], rtol=0, atol=1e-11, err_msg="mi")
-        rt = 5e-3 if policy == hip.DEGEN_EPS else 1e-9
+        rt = 1e-9
         fin = np.isfinite(want["colour"]).all()
         for k in ("alpha", "beta", "wrc"):
             np.testing.assert_allclose(got[k], want[k], rtol=rt, atol=1e-12, err_msg=k, equal_nan=True)
@@ -62,7 +68,7 @@ for i in range(cases):
                 for k in ("nbhd_size", "alpha", "beta", "wrc"):
                     print(k, "gpu", got[k][y, x], "oracle", want[k][y, x])
                 print("mi diff max", np.nanmax(np.abs(got["mi"][y, x] - want["mi"][y, x])))
-    print("%3d %s  %2dx%2dx%2d box %2d %-9s sf %-6g policy %d beta %d  maxN %4d bad %d  %s" % (
-        i, "ok  " if ok else "FAIL", W, H, S, box, mode, sf, policy, beta, int(want["nbhd_size"].max()), want["nonfinite_pixels"], why), flush=True)
+    print("%3d %s  %2dx%2dx%2d box %2d %s %-9s sf %-6g policy %d beta %d  maxN %4d bad %d  %s" % (
+        i, "ok  " if ok else "FAIL", W, H, S, box, "d27" if wide else "d19", mode, sf, policy, beta, int(want["nbhd_size"].max()), want["nonfinite_pixels"], why), flush=True)
 print("fuzz_parity: %d cases, %d failures" % (cases, fails))
 sys.exit(1 if fails else 0)
