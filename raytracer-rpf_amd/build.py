@@ -92,5 +92,6 @@ def build_host(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build_host(force=True, verbose=True))
-    print(build(force=True, verbose=True))
+    force = "--force" in sys.argv
+    print(build(force=force, verbose=True))
+    print(build_host(force=force, verbose=True))
