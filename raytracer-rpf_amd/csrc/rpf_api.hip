@@ -159,6 +159,7 @@ int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const void *d_plane
     p.beta_map = d->beta_map; p.policy = d->degenerate_policy;
     p.fast_weights = (d->flags & RPF_FLAG_FAST_WEIGHTS) ? 1 : 0;
     p.stage_mask = ctx->tun.stage_mask; // timing ablation knob (rpf_set_option); results are wrong unless -1
+    p.screen = ctx->tun.screen;
     const int64_t nmax64 = (int64_t)box * box * d->S;
     if (nmax64 > kMaxNbhd) return fail(ctx, RPF_E_UNSUPPORTED, "box*box*S > 65535: neighbourhood too large (16-bit histogram cells, one-byte bin ids)");
     p.nmax = (int)nmax64;
@@ -597,6 +598,7 @@ int32_t rpf_set_option(rpf_ctx *ctx, const char *name, int64_t value) {
     else if (n == "binning" && value >= -1 && value <= 1) t.binning = (int32_t)value;
     else if (n == "waves_per_pixel" && (value == 0 || value == 1 || value == 4)) t.waves_per_pixel = (int32_t)value;
     else if (n == "table_in_lds" && value >= -1 && value <= 1) t.table_in_lds = (int32_t)value;
+    else if (n == "screen" && value >= 0 && value <= 1) t.screen = (int32_t)value;
     else if (n == "lds_pad" && value >= 0 && value <= 160 * 1024) t.lds_pad = (int32_t)value;
     else return fail(ctx, RPF_E_BADARG, "unknown option or value out of range: " + n);
     ctx->bin_valid = false;

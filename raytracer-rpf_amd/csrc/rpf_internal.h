@@ -32,6 +32,7 @@ struct PassParams {
     int32_t beta_map, policy;
     int32_t fast_weights;  // RPF_FLAG_FAST_WEIGHTS: fp32 pair arithmetic in stage 4
     int32_t stage_mask;    // diagnostics only (rpf_set_option "stage_mask"): bit0 stats chain, bit1 bins, bit2 MI, bit3 weights; -1 = all
+    int32_t screen;        // far-pair screen of the four-wave kernels: 0 off, 1 on
     int32_t strip_w;       // pixels per XCD strip of the pixel walk (slab_pixel)
     int32_t nmax;          // box*box*S: capacity of a neighbourhood
     int32_t bmax;          // floor(sqrt(nmax)): max histogram bins per axis
@@ -63,7 +64,8 @@ struct Tuning {
     int32_t lds_pad = 0;         // extra LDS bytes per workgroup (occupancy experiments)
     int32_t binning = -1;        // -1 auto (box*box*S > 512), 0 / 1
     int32_t stage_mask = -1;     // bit0 stats chain, bit1 bins, bit2 MI, bit3 weights; -1 = all
-    bool is_default() const { return waves_per_pixel == 0 && table_in_lds == -1 && lds_pad == 0 && binning == -1 && stage_mask == -1; }
+    int32_t screen = 1;          // far-pair screen (stage 4, four-wave kernels): 0 off, 1 on; same results
+    bool is_default() const { return waves_per_pixel == 0 && table_in_lds == -1 && lds_pad == 0 && binning == -1 && stage_mask == -1 && screen == 1; }
 };
 
 struct LdsLayout {

@@ -185,7 +185,11 @@ __device__ __forceinline__ void zero_cells(uint32_t *h, int cells, int lane) {
         if constexpr (ZN == 3) h[256 + lane] = 0u;
         if constexpr (ZN == 4) *reinterpret_cast<uint2 *>(h + 256 + lane * 2) = make_uint2(0u, 0u);
     } else {
-        for (int t = lane * 4; t < cells; t += kWave * 4) *reinterpret_cast<uint4 *>(h + t) = make_uint4(0u, 0u, 0u, 0u);
+        // whole 1-KiB wave stores, the same number in every lane: the histogram buffers are padded to a multiple of
+        // 1 KiB (lds_layout).  A per-lane bound makes this a divergent loop, and at the register pressure of the
+        // large-K kernels hipcc parked spill copies behind its exit, where EXEC is empty (check_spills.py).
+        const int nit = __builtin_amdgcn_readfirstlane((cells + kWave * 4 - 1) / (kWave * 4));
+        for (int it = 0; it < nit; ++it) *reinterpret_cast<uint4 *>(h + (it * kWave + lane) * 4) = make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
@@ -491,14 +495,15 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun
     const uint32_t bins = K <= 8 ? align_up((uint32_t)kNDim * kWave * 5u, 16)          // 5-bit words + slot-6 bytes
                                  : align_up((uint32_t)kNDim * kWave * KW * 4u, 16);     // 5- or 6-bit fields in KW words
     uint32_t uni = bins > stage ? bins : stage;
-    const uint32_t fastz = align_up((uint32_t)S * ((kNWt + 2u) & ~1u) * 8u, 16);         // own rows of the weight stage
+    uint32_t fastz = align_up((uint32_t)S * ((kNWt + 2u) & ~1u) * 8u, 16);               // own rows of the weight stage
+    if (nw > 1) fastz += align_up(((uint32_t)S + 1u) / 2u * (2u * ((kNWt + 2u) & ~1u)) * 4u, 16); // + the far-pair screen's fp32 rows, two own samples interleaved
     if (fastz > uni) uni = fastz;
     o += uni;
     L.off_hist = o;
     uint32_t cells = (uint32_t)bmax * (uint32_t)bmax;
     if (K <= 8 && cells < 512u) cells = 512u; // mi_stage clears with unconditional 1-KiB stores
     if (cells < 256u) cells = 256u;           // the buffer doubles as scratch (stage 1b masks, stage 3c, flags)
-    L.hist_stride = align_up(cells * 4u, 16);
+    L.hist_stride = align_up(cells * 4u, 1024);   // zero_cells clears whole 1-KiB rows
     o += L.hist_stride * (uint32_t)nw;        // one histogram buffer per wave of the pixel
     if (tun.lds_pad > 0) o += (uint32_t)tun.lds_pad; // occupancy experiment knob
     L.total = o;

@@ -384,6 +384,27 @@ def test_waves_per_pixel_variants_agree(ctx, hipmod, oracle, S, nw):
         ctx.set_option("no_such_option", 1)
 
 
+@pytest.mark.parametrize("S,mode,layout", [(32, "smooth", 19), (64, "clustered", 19), (32, "smooth", 27)])
+def test_far_pair_screen_changes_nothing(ctx, hipmod, S, mode, layout):
+    """the four-wave kernels skip the fp64 exponent / exp() of a pair of own samples where an fp32 bound proves that
+    every lane's weight underflows to 0.0: with the screen off the filtered colours must be the same BITS"""
+    W, H = 12, 9
+    kw = dict(n_random=4, n_feat=18, dtype="f16") if layout == 27 else {}
+    planes = fb.synth_planes(W, H, S, seed=57 + S, sigma_f=0.05, sigma_c=1e-3, mode=mode, **kw)
+    dkw = dict(n_random=4, n_feat=18, plane_dtype=hipmod.PLANES_F16) if layout == 27 else {}
+    desc = hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS, **dkw)
+    on = ctx.filter_pass_debug(planes, desc, box=7)
+    ctx.set_option("screen", 0)
+    try:
+        off = ctx.filter_pass_debug(planes, desc, box=7)
+        assert ctx.counters().options_active == 1
+    finally:
+        ctx.set_option("screen", 1)
+    assert on["max_nbhd"] > 832  # the four-wave kernels ran
+    assert np.array_equal(on["colour"], off["colour"], equal_nan=True)
+    assert on["nonfinite_pixels"] == off["nonfinite_pixels"]
+
+
 def test_small_neighbourhood_paths_vs_oracle(ctx, hipmod, oracle):
     """N <= 64 (mi_stage_tiny) and 64 < N <= 128 (mi_stage_deep): tiny in-pixel jitter makes the 3-sigma test
     reject most neighbours, the regime of real path-traced buffers"""
