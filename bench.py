@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--no-scaling-4k32", action="store_true", help="skip the strong-scaling 3840x2160x32 object")
     ap.add_argument("--fast-weights", action="store_true", help="opt-in fp32 pair weights (RPF_FLAG_FAST_WEIGHTS)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
-                    help="rpf_set_option override (diagnostics: stage_mask, binning, waves_per_pixel, table_in_lds, lds_pad)")
+                    help="rpf_set_option override (diagnostics: stage_mask, binning, waves_per_pixel, table_in_lds, lds_pad, screen)")
     ap.add_argument("--allow-nonfinite", action="store_true", help="profiling variants whose results are wrong on purpose")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -273,7 +273,7 @@ def main():
                                        "rel_l2_vs_f64_path": rel}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not layout:
-        # the headline buffer is the near-identity regime (every cross weight underflows), so its GPU-vs-oracle
+        # the headline buffer is close to the identity regime (most cross weights underflow), so its GPU-vs-oracle
         # figure says little about stage 4: the same comparison on a small filter-ACTIVE buffer (clustered generator)
         import numpy as np
         import pyoracle as O

@@ -992,7 +992,9 @@ int32_t rpf_multi_filter(rpf_multi *m, const rpf_desc *d, const void *planes_v, 
                         e1 = hipMemcpyAsync(dst1, src1, hb * sizeof(double), hipMemcpyDeviceToDevice, up->stream);
                         e2 = hipMemcpyAsync(dst2, src2, ht * sizeof(double), hipMemcpyDeviceToDevice, up->stream);
                     } else {
+                        (void)hipSetDevice(up->device); // each copy is queued with its stream's device current
                         e1 = hipMemcpyPeerAsync(dst1, up->device, src1, dn->device, hb * sizeof(double), up->stream);
+                        (void)hipSetDevice(dn->device);
                         e2 = hipMemcpyPeerAsync(dst2, dn->device, src2, up->device, ht * sizeof(double), dn->stream);
                     }
                     if (e1 != hipSuccess || e2 != hipSuccess)
