@@ -285,6 +285,15 @@ def main():
         out["parity_probe"] = {"buffer": "clustered %dx%dx%d, sigma_f=1e-3 (filter-active)" % (Wp, Hp, Sp),
                                "activity_rel_l2": float(np.linalg.norm(want - cin) / np.linalg.norm(cin)),
                                "gpu_vs_oracle_rel_l2": float(np.linalg.norm(got - want) / np.linalg.norm(want))}
+        # ... and on a 32-spp buffer, whose neighbourhoods (~1500 samples) run the four-wave kernels and their far-pair screen
+        Wq, Hq, Sq = 48, 20, 32
+        pl = fb.synth_planes(Wq, Hq, Sq, seed=12, sigma_f=0.02, sigma_c=0.01, mode="clustered")
+        r = ctx.filter_pass_debug(pl, hip.make_desc(Wq, Hq, Sq), box=box, debug=False)
+        want = O.filter_pass(pl, O.make_desc(Wq, Hq, Sq, box=box), debug=False)["colour"]
+        cin = pl[2:5].astype(np.float64)
+        out["parity_probe_32spp"] = {"buffer": "clustered %dx%dx%d, sigma_f=0.02" % (Wq, Hq, Sq), "max_nbhd": int(r["max_nbhd"]),
+                                     "activity_rel_l2": float(np.linalg.norm(want - cin) / np.linalg.norm(cin)),
+                                     "gpu_vs_oracle_rel_l2": float(np.linalg.norm(r["colour"] - want) / np.linalg.norm(want))}
 
     # ---- strong scaling of BASELINE configs[3]: 3840x2160x32 spp row-tiled over the N ranks ---------------------------
     if args.workload == "cfg2" and not args.no_scaling_4k32 and not args.option:
