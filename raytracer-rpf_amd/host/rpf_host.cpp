@@ -146,7 +146,39 @@ int RPFFilter::run(SamplingFilm &film, const std::vector<int> &boxes, std::vecto
     return st;
 }
 
+std::string RPFParams::Parse(const int *boxsizes, int n_boxsizes, const char *backend, RPFParams *out) {
+    RPFParams r; // defaults = the reference's hard-coded constants
+    if (boxsizes != nullptr && n_boxsizes > 0) {
+        if (n_boxsizes > RPF_MAX_BOXES)
+            return "\"boxsizes\" holds " + std::to_string(n_boxsizes) + " values; at most " + std::to_string(RPF_MAX_BOXES) + " filter passes are supported";
+        r.boxsizes.assign(boxsizes, boxsizes + n_boxsizes);
+        for (int b : r.boxsizes)
+            if (b < 1 || (b & 1) == 0)
+                return "\"boxsizes\" value " + std::to_string(b) + " is not an odd positive window width (rpf.cpp:561 centres the window on the pixel)";
+    }
+    const std::string be = backend ? backend : "hip";
+    if (be == "hip") r.backend = HIP;
+    else if (be == "reference") r.backend = REFERENCE;
+    else return "unknown \"backend\" \"" + be + "\" (expected \"hip\" or \"reference\")";
+    if (out) *out = r;
+    return std::string();
+}
+
 } // namespace rpf_host
+
+extern "C" int32_t rpf_host_parse_params(const int32_t *boxsizes, int32_t n_boxsizes, const char *backend, int32_t *boxes_out,
+                                         int32_t *n_out, int32_t *backend_out, char *err, int32_t err_len) {
+    rpf_host::RPFParams prm;
+    const std::string e = rpf_host::RPFParams::Parse(boxsizes, n_boxsizes, backend, &prm);
+    if (!e.empty()) {
+        if (err && err_len > 0) std::snprintf(err, err_len, "%s", e.c_str());
+        return -1;
+    }
+    if (boxes_out) for (size_t i = 0; i < prm.boxsizes.size(); ++i) boxes_out[i] = prm.boxsizes[i];
+    if (n_out) *n_out = (int32_t)prm.boxsizes.size();
+    if (backend_out) *backend_out = (int32_t)prm.backend;
+    return 0;
+}
 
 extern "C" int32_t rpf_host_apply_filter_aos(double *aos, const float *ray_weight, int32_t W, int32_t H, int32_t S,
                                              const int32_t *box_sizes, int32_t n_box, int32_t beta_map, int32_t policy,

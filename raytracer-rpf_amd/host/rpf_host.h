@@ -42,6 +42,22 @@ struct SamplingFilm {
 
 class RPFFilter;
 
+// Optional scene-file parameters of the "rpf" integrator.  CreateRPFIntegrator (rpf.cpp:941-966) reads only the path
+// tracer's keys and the filter's constants are hard-coded (box sizes {7}, rpf.cpp:767; the commented alternative
+// {55, 35, 17, 7} beside it); these two keys make them reachable from a scene file while a file without them renders
+// exactly as before ("Config / flags"):
+//     "integer boxsizes" [ 7 ]      one filter pass per entry, in order; odd, >= 1, at most RPF_MAX_BOXES entries
+//     "string backend"   "hip"      "hip": this library; "reference": pbrt's own CPU ApplyRPFFilter loop stays in charge
+//                                   (nothing of this library runs -- there is no CPU path inside it)
+// Parse() takes what pbrt's ParamSet hands out -- FindInt("boxsizes", &n) and FindOneString("backend", "hip") -- and
+// returns "" or a message for pbrt's Error().
+struct RPFParams {
+    enum Backend { HIP = 0, REFERENCE = 1 };
+    std::vector<int> boxsizes{7};
+    Backend backend = HIP;
+    static std::string Parse(const int *boxsizes, int n_boxsizes, const char *backend, RPFParams *out);
+};
+
 // Page-locked array handed out by the filter's context (rpf_host_alloc); grow-only, released with its owner.
 template <class T>
 class PinnedArray {
@@ -149,6 +165,9 @@ int32_t rpf_host_apply_filter_aos(double *aos, const float *ray_weight, int32_t 
                                   int32_t device, float *pixel_rgb_out, char *err, int32_t err_len);
 // same input, but the samples are pushed into a PlaneFilm by concurrent 16x16-tile producers (as pbrt's render
 // tiles would); sample_rgb_out float [3][H][W][S], pixel_rgb_out float [H][W][3], either may be NULL.
+// RPFParams::Parse through a C doorway: boxes_out[RPF_MAX_BOXES]; returns 0 or -1 with the message in err
+int32_t rpf_host_parse_params(const int32_t *boxsizes, int32_t n_boxsizes, const char *backend, int32_t *boxes_out,
+                              int32_t *n_out, int32_t *backend_out, char *err, int32_t err_len);
 int32_t rpf_host_planefilm_filter(const double *aos, const float *ray_weight, int32_t W, int32_t H, int32_t S,
                                   const int32_t *box_sizes, int32_t n_box, int32_t beta_map, int32_t policy,
                                   int32_t device, float *sample_rgb_out, float *pixel_rgb_out, char *err, int32_t err_len);

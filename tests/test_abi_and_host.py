@@ -122,3 +122,28 @@ def test_oracle_feature_images_follow_visualizeSF(oracle):
     assert img.shape == (6, 1, 2, 3)
     assert list(img[0, 0, :, 0]) == [0.5, 1.0] and (img[0, 0, :, 1] == 0).all()
     assert list(img[4, 0, :, 0]) == [0.5 / 1.5, 1.0] and (img[4, 0, :, 2] == 0).all()
+
+
+def test_optional_integrator_parameters(hipmod):
+    """the "rpf" integrator takes only the path tracer's keys (rpf.cpp:946-963) and hard-codes the box
+    list {7} (rpf.cpp:767); the host mirror accepts optional "integer boxsizes" / "string backend" with those defaults"""
+    lib = C.CDLL(os.path.join(os.path.dirname(hipmod.LIB_PATH), "librpf_host.so"))
+    lib.rpf_host_parse_params.restype = C.c_int32
+
+    def parse(boxes, backend):
+        arr = (C.c_int32 * max(len(boxes), 1))(*boxes) if boxes is not None else None
+        out, n, be = (C.c_int32 * 8)(), C.c_int32(0), C.c_int32(-1)
+        err = C.create_string_buffer(256)
+        st = lib.rpf_host_parse_params(arr, len(boxes) if boxes is not None else 0,
+                                       backend.encode() if backend is not None else None, out, C.byref(n), C.byref(be), err, 256)
+        return st, list(out[:n.value]), be.value, err.value.decode()
+
+    assert parse(None, None) == (0, [7], 0, "")                       # a scene file without the keys: the reference's constants
+    assert parse([55, 35, 17, 7], "hip") == (0, [55, 35, 17, 7], 0, "")  # the list commented out at rpf.cpp:767
+    assert parse([7, 7, 5, 5], "reference")[:3] == (0, [7, 7, 5, 5], 1)
+    st, _, _, msg = parse([7, 6], "hip")
+    assert st == -1 and "6" in msg and "odd" in msg
+    st, _, _, msg = parse([3] * 9, "hip")
+    assert st == -1 and "at most 8" in msg
+    st, _, _, msg = parse([7], "cuda")
+    assert st == -1 and "cuda" in msg
