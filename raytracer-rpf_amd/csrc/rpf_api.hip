@@ -163,11 +163,16 @@ int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const void *d_plane
     const int64_t nmax64 = (int64_t)box * box * d->S;
     if (nmax64 > kMaxNbhd) return fail(ctx, RPF_E_UNSUPPORTED, "box*box*S > 65535: neighbourhood too large (16-bit histogram cells, one-byte bin ids)");
     p.nmax = (int)nmax64;
-    {   // XCD strip width: box rows x (strip + halo) px x S samples x ~88 B should use about a quarter of the 4 MiB L2
+    {   // XCD strip width: box rows x (strip + halo) px x S samples x ~88 B against a budget of L2 bytes.  Measured
+        // (scripts/strip_sweep.sh, profiles/r02_strip_width.txt): the kernel time does not depend on it, the fetched bytes
+        // do -- at 8 spp wide strips win (a quarter of the 4 MiB L2: 128 px), from 16 spp up narrow ones (the size-binned
+        // route reads every window twice, count pass and filter pass, several hundred microseconds apart): 256 KiB.
         const int64_t per_px = (int64_t)box * d->S * 88;
-        int w = (int)((1 << 20) / std::max<int64_t>(per_px, 1)) - 2 * ((box - 1) / 2);
+        const int64_t budget = d->S > 8 ? (256 << 10) : (1 << 20);
+        int w = (int)(budget / std::max<int64_t>(per_px, 1)) - 2 * ((box - 1) / 2);
         w = std::max(8, std::min(128, w));
         p.strip_w = w & ~7;
+        if (ctx->tun.strip_w > 0) p.strip_w = ctx->tun.strip_w;
     }
     p.bmax = (int)std::sqrt((double)p.nmax);
     if (p.bmax < 1) p.bmax = 1;
@@ -599,6 +604,7 @@ int32_t rpf_set_option(rpf_ctx *ctx, const char *name, int64_t value) {
     else if (n == "waves_per_pixel" && (value == 0 || value == 1 || value == 4)) t.waves_per_pixel = (int32_t)value;
     else if (n == "table_in_lds" && value >= -1 && value <= 1) t.table_in_lds = (int32_t)value;
     else if (n == "screen" && value >= 0 && value <= 1) t.screen = (int32_t)value;
+    else if (n == "strip_w" && value >= 0 && value <= 4096 && value % 8 == 0) t.strip_w = (int32_t)value;
     else if (n == "lds_pad" && value >= 0 && value <= 160 * 1024) t.lds_pad = (int32_t)value;
     else return fail(ctx, RPF_E_BADARG, "unknown option or value out of range: " + n);
     ctx->bin_valid = false;

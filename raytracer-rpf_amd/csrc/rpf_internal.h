@@ -65,7 +65,8 @@ struct Tuning {
     int32_t binning = -1;        // -1 auto (box*box*S > 512), 0 / 1
     int32_t stage_mask = -1;     // bit0 stats chain, bit1 bins, bit2 MI, bit3 weights; -1 = all
     int32_t screen = 1;          // far-pair screen (stage 4, four-wave kernels): 0 off, 1 on; same results
-    bool is_default() const { return waves_per_pixel == 0 && table_in_lds == -1 && lds_pad == 0 && binning == -1 && stage_mask == -1 && screen == 1; }
+    int32_t strip_w = 0;         // pixels per XCD strip of the pixel walk: 0 auto (by box and spp), else a multiple of 8; same results
+    bool is_default() const { return waves_per_pixel == 0 && table_in_lds == -1 && lds_pad == 0 && binning == -1 && stage_mask == -1 && screen == 1 && strip_w == 0; }
 };
 
 struct LdsLayout {
