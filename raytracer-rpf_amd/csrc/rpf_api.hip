@@ -34,6 +34,7 @@ struct rpf_ctx {
     uint64_t *d_dfix = nullptr;  size_t cap_dfix = 0;                         // first differences
     float *d_srgb = nullptr;     size_t cap_srgb = 0;
     float *d_prgb = nullptr;     size_t cap_prgb = 0;
+    double *d_carry = nullptr; size_t cap_carry = 0;       // split 64-spp route: statistics / weights between its two kernels
     int32_t *d_status = nullptr;                           // [0] bad count [1] first bad
     unsigned long long *d_nred = nullptr;                  // [0] sum N [1] max N
     uint32_t *d_lists = nullptr; size_t cap_lists = 0;     // size binning: [7][H*W] pixel lists
@@ -223,6 +224,12 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p, hipStream_t s, i
     if (pc.mask_stride == 0) pc.mask_stride = 1;
     if ((st = ensure(ctx, ctx->d_masks, ctx->cap_masks, HW * pc.mask_stride * sizeof(uint64_t)))) return st;
     pc.masks = ctx->d_masks;
+    pc.carry = nullptr;
+    if (p.nmax > class_capacity(kNumClasses - 3) && p.nmax <= kMaxResident && ctx->tun.split_weights != 0) {
+        // the 64-spp class runs as two kernels (stages 1b .. 3c, then the weights): per-pixel hand-over buffer
+        if ((st = ensure(ctx, ctx->d_carry, ctx->cap_carry, HW * (size_t)kCarryStride * sizeof(double)))) return st;
+        pc.carry = ctx->d_carry;
+    }
     uint32_t counts[kNumClasses];
     if (ctx->bin_valid && ctx->bin_box == p.box && ctx->bin_r0 == p.row_begin && ctx->bin_r1 == p.row_end) {
         std::memcpy(counts, ctx->bin_counts, sizeof(counts));
@@ -517,7 +524,7 @@ void rpf_destroy(rpf_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *bufs[] = {ctx->d_planes, ctx->d_rayw, ctx->d_colA, ctx->d_colB, ctx->d_pmean, ctx->d_pstd, ctx->d_nbhd,
                     ctx->d_tfix, ctx->d_dfix, ctx->d_srgb, ctx->d_prgb, ctx->d_status, ctx->d_nred, ctx->d_lists,
-                    ctx->d_class_counts, ctx->d_masks, ctx->d_big_list, ctx->d_big_bins};
+                    ctx->d_class_counts, ctx->d_masks, ctx->d_big_list, ctx->d_big_bins, ctx->d_carry};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (void *b : ctx->d_dbg)
@@ -604,6 +611,7 @@ int32_t rpf_set_option(rpf_ctx *ctx, const char *name, int64_t value) {
     else if (n == "waves_per_pixel" && (value == 0 || value == 1 || value == 4)) t.waves_per_pixel = (int32_t)value;
     else if (n == "table_in_lds" && value >= -1 && value <= 1) t.table_in_lds = (int32_t)value;
     else if (n == "screen" && value >= 0 && value <= 1) t.screen = (int32_t)value;
+    else if (n == "split_weights" && value >= -1 && value <= 1) t.split_weights = (int32_t)value;
     else if (n == "strip_w" && value >= 0 && value <= 4096 && value % 8 == 0) t.strip_w = (int32_t)value;
     else if (n == "lds_pad" && value >= 0 && value <= 160 * 1024) t.lds_pad = (int32_t)value;
     else return fail(ctx, RPF_E_BADARG, "unknown option or value out of range: " + n);

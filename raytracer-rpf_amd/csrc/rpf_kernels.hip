@@ -511,6 +511,29 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun
 }
 
 
+// LDS of the weight kernel of the split 64-spp route (filter_pixel_kernel<.., PHASE 2>): member list, own samples and
+// their rows, the statistics block, 1 KiB of scratch per wave -- no table, no bin ids, no histograms
+LdsLayout lds_layout_weights(int S, int nmax, const SampleLayout &lay) {
+    LdsLayout L{};
+    const uint32_t kNDim = (uint32_t)lay.ndim(), kNPair = (uint32_t)lay.npair(), kNWt = (uint32_t)lay.nwt();
+    uint32_t o = 0;
+    L.off_T = o;
+    L.off_stat = o; o += align_up(4 * kNDim * 8, 16);
+    L.off_hx = o; o += align_up(kNDim * 8, 16);
+    L.off_pair = o; o += align_up(kNPair * 8, 16);
+    L.off_mi = L.off_pair;
+    L.off_own = o; o += align_up((uint32_t)S * kNDim * 8u, 16);
+    L.off_off = o; o += align_up((uint32_t)nmax * 4u, 16);
+    L.off_union = o;
+    o += align_up((uint32_t)S * ((kNWt + 2u) & ~1u) * 8u, 16) + align_up(((uint32_t)S + 1u) / 2u * (2u * ((kNWt + 2u) & ~1u)) * 4u, 16);
+    L.off_hist = o;
+    L.nw = 4;
+    L.hist_stride = 1024;
+    o += L.hist_stride * L.nw;
+    L.total = o;
+    return L;
+}
+
 hipError_t launch_udiv_selftest(uint64_t n, uint64_t seed, int mode, unsigned long long *d_mismatch, hipStream_t s) {
     hipLaunchKernelGGL(udiv_selftest_kernel, dim3(2048), dim3(256), 0, s, n, seed, mode, d_mismatch);
     return hipGetLastError();
@@ -536,7 +559,9 @@ hipError_t launch_filter_pass(const PassParams &p, const Tuning &tun, hipStream_
     const int64_t band = p.pix_list ? (int64_t)((p.list_count + 7u) / 8u)
                                     : (int64_t)((rows_own + 7) / 8) * p.W; // pixels per XCD band (see slab_pixel)
     const unsigned grid = (unsigned)(band * 8);
-    return p.lay.is_ref19() ? d19::impl_filter(p, L, t_in_lds, grid, s) : d27::impl_filter(p, L, t_in_lds, grid, s);
+    LdsLayout L2{}; // weight kernel of the split 64-spp route (total == 0: not split)
+    if (p.carry != nullptr && tun.split_weights != 0 && L.nw == 4 && samples_per_lane(p.nmax) == 49) L2 = lds_layout_weights(p.S, p.nmax, p.lay);
+    return p.lay.is_ref19() ? d19::impl_filter(p, L, L2, t_in_lds, grid, s) : d27::impl_filter(p, L, L2, t_in_lds, grid, s);
 }
 
 int class_capacity(int c) {
