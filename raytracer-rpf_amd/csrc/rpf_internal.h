@@ -47,7 +47,7 @@ struct PassParams {
     const uint64_t *tfix;  // round(k ln k * 2^44), k = 0..nmax
     const uint64_t *dfix;  // tfix[k+1] - tfix[k], k = 0..nmax-1
     int32_t *nbhd;         // [H*W] N per pixel (always written)
-    double *carry;            // split 64-spp route: per-pixel statistics and weights between its two kernels (80 doubles per pixel), or null
+    double *carry;            // split 64-spp route: per-pixel statistics and weights between its two kernels (kCarryStride doubles per pixel), or null
     const uint32_t *pix_list; // size-binned launch: the pixels (y*W+x) this launch filters, or null = every pixel of the slab
     uint32_t list_count;
     uint64_t *masks;       // size-binned launch: acceptance masks of stage 1b, [H*W][mask_stride] (one per 64 candidates,
@@ -78,7 +78,8 @@ struct LdsLayout {
 };
 LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun, const SampleLayout &lay);
 LdsLayout lds_layout_weights(int S, int nmax, const SampleLayout &lay); // the weight kernel of the split 64-spp route
-constexpr int kCarryStride = 80; // doubles per pixel of PassParams::carry (>= kCarry of either layout)
+LdsLayout lds_layout_chains(int S, int nmax, const SampleLayout &lay);  // ... and its chain kernel
+constexpr int kCarryStride = 136; // doubles per pixel of PassParams::carry (>= kCarry of either layout)
 int samples_per_lane(int nmax); // the K the filter kernel is instantiated with (0 = unsupported)
 bool table_in_lds(int S, int nmax, int bmax, const Tuning &tun, const SampleLayout &lay);
 int waves_per_pixel(int nmax, const Tuning &tun);

@@ -534,6 +534,28 @@ LdsLayout lds_layout_weights(int S, int nmax, const SampleLayout &lay) {
     return L;
 }
 
+// ... and of its chain kernel (PHASE 3): member list, own samples, the producers' staging chunks, 2 KiB of scratch per wave
+LdsLayout lds_layout_chains(int S, int nmax, const SampleLayout &lay) {
+    LdsLayout L{};
+    const uint32_t kNDim = (uint32_t)lay.ndim(), kNPair = (uint32_t)lay.npair();
+    uint32_t o = 0;
+    L.off_T = o;
+    L.off_stat = o; o += align_up(4 * kNDim * 8, 16);
+    L.off_hx = o; o += align_up(kNDim * 8, 16);
+    L.off_pair = o; o += align_up(kNPair * 8, 16);
+    L.off_mi = L.off_pair;
+    L.off_own = o; o += align_up((uint32_t)S * kNDim * 8u, 16);
+    L.off_off = o; o += align_up((uint32_t)nmax * 4u, 16);
+    L.off_union = o;
+    L.nw = 4;
+    o += align_up((L.nw - 2) * kNDim * (kStageChunk + 1) * 8u, 16); // one staged chunk per producer wave
+    L.off_hist = o;
+    L.hist_stride = 2048;
+    o += L.hist_stride * L.nw;
+    L.total = o;
+    return L;
+}
+
 hipError_t launch_udiv_selftest(uint64_t n, uint64_t seed, int mode, unsigned long long *d_mismatch, hipStream_t s) {
     hipLaunchKernelGGL(udiv_selftest_kernel, dim3(2048), dim3(256), 0, s, n, seed, mode, d_mismatch);
     return hipGetLastError();
@@ -560,8 +582,12 @@ hipError_t launch_filter_pass(const PassParams &p, const Tuning &tun, hipStream_
                                     : (int64_t)((rows_own + 7) / 8) * p.W; // pixels per XCD band (see slab_pixel)
     const unsigned grid = (unsigned)(band * 8);
     LdsLayout L2{}; // weight kernel of the split 64-spp route (total == 0: not split)
-    if (p.carry != nullptr && tun.split_weights != 0 && L.nw == 4 && samples_per_lane(p.nmax) == 49) L2 = lds_layout_weights(p.S, p.nmax, p.lay);
-    return p.lay.is_ref19() ? d19::impl_filter(p, L, L2, t_in_lds, grid, s) : d27::impl_filter(p, L, L2, t_in_lds, grid, s);
+    LdsLayout L3{}; // ... and of its chain kernel
+    if (p.carry != nullptr && tun.split_weights != 0 && L.nw == 4 && samples_per_lane(p.nmax) == 49) {
+        L2 = lds_layout_weights(p.S, p.nmax, p.lay);
+        L3 = lds_layout_chains(p.S, p.nmax, p.lay);
+    }
+    return p.lay.is_ref19() ? d19::impl_filter(p, L, L2, L3, t_in_lds, grid, s) : d27::impl_filter(p, L, L2, L3, t_in_lds, grid, s);
 }
 
 int class_capacity(int c) {
