@@ -225,8 +225,8 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p, hipStream_t s, i
     if ((st = ensure(ctx, ctx->d_masks, ctx->cap_masks, HW * pc.mask_stride * sizeof(uint64_t)))) return st;
     pc.masks = ctx->d_masks;
     pc.carry = nullptr;
-    if (p.nmax > class_capacity(kNumClasses - 3) && p.nmax <= kMaxResident && ctx->tun.split_weights != 0) {
-        // the 64-spp class runs as two kernels (stages 1b .. 3c, then the weights): per-pixel hand-over buffer
+    if (p.nmax > class_capacity(kNumClasses - 4) && p.nmax <= kMaxResident && ctx->tun.split_weights != 0) {
+        // the 32- and 64-spp classes run as three kernels (chains; bins + MI; weights): per-pixel hand-over buffer
         if ((st = ensure(ctx, ctx->d_carry, ctx->cap_carry, HW * (size_t)kCarryStride * sizeof(double)))) return st;
         pc.carry = ctx->d_carry;
     }

@@ -77,7 +77,7 @@ struct LdsLayout {
     uint32_t nw;          // waves per pixel (1 or 4)
 };
 LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun, const SampleLayout &lay);
-LdsLayout lds_layout_weights(int S, int nmax, const SampleLayout &lay); // the weight kernel of the split 64-spp route
+LdsLayout lds_layout_weights(int S, int nmax, const SampleLayout &lay, int nw); // the weight kernel of the split 64-spp route
 LdsLayout lds_layout_chains(int S, int nmax, const SampleLayout &lay);  // ... and its chain kernel
 constexpr int kCarryStride = 136; // doubles per pixel of PassParams::carry (>= kCarry of either layout)
 int samples_per_lane(int nmax); // the K the filter kernel is instantiated with (0 = unsupported)

@@ -513,7 +513,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun
 
 // LDS of the weight kernel of the split 64-spp route (filter_pixel_kernel<.., PHASE 2>): member list, own samples and
 // their rows, the statistics block, 1 KiB of scratch per wave -- no table, no bin ids, no histograms
-LdsLayout lds_layout_weights(int S, int nmax, const SampleLayout &lay) {
+LdsLayout lds_layout_weights(int S, int nmax, const SampleLayout &lay, int nw) {
     LdsLayout L{};
     const uint32_t kNDim = (uint32_t)lay.ndim(), kNPair = (uint32_t)lay.npair(), kNWt = (uint32_t)lay.nwt();
     uint32_t o = 0;
@@ -527,7 +527,7 @@ LdsLayout lds_layout_weights(int S, int nmax, const SampleLayout &lay) {
     L.off_union = o;
     o += align_up((uint32_t)S * ((kNWt + 2u) & ~1u) * 8u, 16) + align_up(((uint32_t)S + 1u) / 2u * (2u * ((kNWt + 2u) & ~1u)) * 4u, 16);
     L.off_hist = o;
-    L.nw = 4;
+    L.nw = (uint32_t)nw;
     L.hist_stride = 1024;
     o += L.hist_stride * L.nw;
     L.total = o;
@@ -583,8 +583,9 @@ hipError_t launch_filter_pass(const PassParams &p, const Tuning &tun, hipStream_
     const unsigned grid = (unsigned)(band * 8);
     LdsLayout L2{}; // weight kernel of the split 64-spp route (total == 0: not split)
     LdsLayout L3{}; // ... and of its chain kernel
-    if (p.carry != nullptr && tun.split_weights != 0 && L.nw == 4 && samples_per_lane(p.nmax) == 49) {
-        L2 = lds_layout_weights(p.S, p.nmax, p.lay);
+    if (p.carry != nullptr && tun.split_weights != 0 && L.nw == 4 && samples_per_lane(p.nmax) >= 25) {
+        const int sweeps = (p.S + (p.lay.is_ref19() ? 15 : 7)) / (p.lay.is_ref19() ? 16 : 8); // own samples per sweep of the weight kernel
+        L2 = lds_layout_weights(p.S, p.nmax, p.lay, sweeps <= 2 ? 2 : 4);
         L3 = lds_layout_chains(p.S, p.nmax, p.lay);
     }
     return p.lay.is_ref19() ? d19::impl_filter(p, L, L2, L3, t_in_lds, grid, s) : d27::impl_filter(p, L, L2, L3, t_in_lds, grid, s);
