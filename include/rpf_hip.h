@@ -165,8 +165,9 @@ int32_t rpf_filter_ex(rpf_ctx *ctx, const rpf_desc *desc, const void *planes, co
  *   "waves_per_pixel"  0 auto, 1, 4 (4 needs box*box*S > 832)
  *   "table_in_lds"     -1 auto, 0, 1
  *   "lds_pad"          extra LDS bytes per workgroup (lowers occupancy)
- *   "split_weights"    64-spp size class: run the weight stage as a second kernel at twice the occupancy: -1 auto
- *                      (default: on), 0 off, 1 on; same results
+ *   "split_weights"    32- and 64-spp size classes: three launches (in-order chains; bins + MI; weights) instead of one
+ *                      kernel, the light stages at two to three times the occupancy: -1 auto (default: on), 0 off, 1 on;
+ *                      same results bit for bit
  *   "strip_w"          pixels per XCD strip of the pixel walk: 0 auto (default), else a multiple of 8; same results
  *   "screen"           far-pair screen of the weight stage (four-wave kernels): 1 on (default), 0 off.  Both settings
  *                      give the same filtered colours bit for bit.

@@ -34,7 +34,7 @@ struct rpf_ctx {
     uint64_t *d_dfix = nullptr;  size_t cap_dfix = 0;                         // first differences
     float *d_srgb = nullptr;     size_t cap_srgb = 0;
     float *d_prgb = nullptr;     size_t cap_prgb = 0;
-    double *d_carry = nullptr; size_t cap_carry = 0;       // split 64-spp route: statistics / weights between its two kernels
+    double *d_carry = nullptr; size_t cap_carry = 0;       // split route of the 32- / 64-spp classes: statistics / weights between its three kernels
     int32_t *d_status = nullptr;                           // [0] bad count [1] first bad
     unsigned long long *d_nred = nullptr;                  // [0] sum N [1] max N
     uint32_t *d_lists = nullptr; size_t cap_lists = 0;     // size binning: [7][H*W] pixel lists

@@ -47,7 +47,7 @@ struct PassParams {
     const uint64_t *tfix;  // round(k ln k * 2^44), k = 0..nmax
     const uint64_t *dfix;  // tfix[k+1] - tfix[k], k = 0..nmax-1
     int32_t *nbhd;         // [H*W] N per pixel (always written)
-    double *carry;            // split 64-spp route: per-pixel statistics and weights between its two kernels (kCarryStride doubles per pixel), or null
+    double *carry;            // split route of the 32- / 64-spp classes: per-pixel statistics and weights between its three kernels (kCarryStride doubles per pixel), or null
     const uint32_t *pix_list; // size-binned launch: the pixels (y*W+x) this launch filters, or null = every pixel of the slab
     uint32_t list_count;
     uint64_t *masks;       // size-binned launch: acceptance masks of stage 1b, [H*W][mask_stride] (one per 64 candidates,
@@ -66,7 +66,7 @@ struct Tuning {
     int32_t binning = -1;        // -1 auto (box*box*S > 512), 0 / 1
     int32_t stage_mask = -1;     // bit0 stats chain, bit1 bins, bit2 MI, bit3 weights; -1 = all
     int32_t screen = 1;          // far-pair screen (stage 4, four-wave kernels): 0 off, 1 on; same results
-    int32_t split_weights = -1;  // 64-spp class: weights in a second kernel: -1 auto (on), 0 off, 1 on; same results
+    int32_t split_weights = -1;  // 32- / 64-spp classes as three kernels (chains; bins + MI; weights): -1 auto (on), 0 off, 1 on; same results
     int32_t strip_w = 0;         // pixels per XCD strip of the pixel walk: 0 auto (by box and spp), else a multiple of 8; same results
     bool is_default() const { return waves_per_pixel == 0 && table_in_lds == -1 && lds_pad == 0 && binning == -1 && stage_mask == -1 && screen == 1 && strip_w == 0 && split_weights == -1; }
 };
@@ -77,7 +77,7 @@ struct LdsLayout {
     uint32_t nw;          // waves per pixel (1 or 4)
 };
 LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun, const SampleLayout &lay);
-LdsLayout lds_layout_weights(int S, int nmax, const SampleLayout &lay, int nw); // the weight kernel of the split 64-spp route
+LdsLayout lds_layout_weights(int S, int nmax, const SampleLayout &lay, int nw); // the weight kernel of the split route (32- / 64-spp classes)
 LdsLayout lds_layout_chains(int S, int nmax, const SampleLayout &lay);  // ... and its chain kernel
 constexpr int kCarryStride = 136; // doubles per pixel of PassParams::carry (>= kCarry of either layout)
 int samples_per_lane(int nmax); // the K the filter kernel is instantiated with (0 = unsupported)

@@ -511,7 +511,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun
 }
 
 
-// LDS of the weight kernel of the split 64-spp route (filter_pixel_kernel<.., PHASE 2>): member list, own samples and
+// LDS of the weight kernel of the split route of the 32- / 64-spp classes (filter_pixel_kernel<.., PHASE 2>): member list, own samples and
 // their rows, the statistics block, 1 KiB of scratch per wave -- no table, no bin ids, no histograms
 LdsLayout lds_layout_weights(int S, int nmax, const SampleLayout &lay, int nw) {
     LdsLayout L{};
@@ -581,7 +581,7 @@ hipError_t launch_filter_pass(const PassParams &p, const Tuning &tun, hipStream_
     const int64_t band = p.pix_list ? (int64_t)((p.list_count + 7u) / 8u)
                                     : (int64_t)((rows_own + 7) / 8) * p.W; // pixels per XCD band (see slab_pixel)
     const unsigned grid = (unsigned)(band * 8);
-    LdsLayout L2{}; // weight kernel of the split 64-spp route (total == 0: not split)
+    LdsLayout L2{}; // weight kernel of the split route (total == 0: not split)
     LdsLayout L3{}; // ... and of its chain kernel
     if (p.carry != nullptr && tun.split_weights != 0 && L.nw == 4 && samples_per_lane(p.nmax) >= 25) {
         const int sweeps = (p.S + (p.lay.is_ref19() ? 15 : 7)) / (p.lay.is_ref19() ? 16 : 8); // own samples per sweep of the weight kernel
