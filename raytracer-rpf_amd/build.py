@@ -9,9 +9,12 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB = os.path.join(_HERE, "lib", "librpf_hip.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("rpf_kernels.hip", "rpf_api.hip")]
+# the fused per-pixel kernels compile as one translation unit per sample layout and size-class part (rpf_filter_impl.inc
+# with RPF_IMPL_PART = 1 / 2 / 3), in parallel: the single kernel TU of rounds 1-2 took 3.2 minutes
+KERNEL_TUS = ["rpf_impl_%s_%s.hip" % (lay, part) for lay in ("d19", "d27") for part in ("small", "mid", "large")] + ["rpf_kernels.hip"]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in KERNEL_TUS + ["rpf_api.hip"]]
 HEADERS = [os.path.join(_HERE, "csrc", "rpf_internal.h"), os.path.join(_HERE, "csrc", "rpf_xlane.h"),
-           os.path.join(_HERE, "csrc", "rpf_filter_impl.inc"),
+           os.path.join(_HERE, "csrc", "rpf_filter_impl.inc"), os.path.join(_HERE, "csrc", "rpf_device_common.h"),
            os.path.join(_ROOT, "include", "rpf_hip.h")]
 
 
@@ -31,7 +34,7 @@ def is_stale():
 
 
 def build(force=False, verbose=False):
-    """one object per translation unit (the kernel TU takes minutes, the ABI TU seconds), then the link"""
+    """one object per translation unit, compiled in parallel, then the link"""
     if not force and not is_stale():
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
@@ -52,7 +55,7 @@ def build(force=False, verbose=False):
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
     import glob
-    asm = [f for f in glob.glob(os.path.join(OBJ_DIR, "*gfx950*.s")) if "rpf_kernels" in os.path.basename(f)]
+    asm = sorted(f for f in glob.glob(os.path.join(OBJ_DIR, "*gfx950*.s")) if "rpf_api" not in os.path.basename(f))
     if asm:
         chk = subprocess.run([sys.executable, os.path.join(_ROOT, "scripts", "check_spills.py")] + asm,
                              stdout=subprocess.PIPE, text=True)
