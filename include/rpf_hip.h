@@ -128,6 +128,9 @@ typedef struct rpf_counters {
     float d2h_ms;               /* rpf_filter(): HBM->host                                          */
     int32_t filter_kernel_launches;
     int32_t options_active;     /* 1 when any rpf_set_option override was in force (diagnostic runs)   */
+    int32_t redo_pixels;        /* RPF_DEGEN_REF_ABORT, last pass: pixels filtered a second time with the reference's own
+                                   floating-point MI expression (an exactly independent histogram pair at a non-power-of-two
+                                   N: mi.cpp:79-86 returns rounding residue there, not 0)                */
 } rpf_counters;
 
 const char *rpf_version(void);
@@ -206,6 +209,11 @@ int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *desc, int32_t box, c
 
 /* counters of the most recent rpf_filter / rpf_filter_device / rpf_filter_pass_debug call */
 int32_t rpf_query_counters(rpf_ctx *ctx, rpf_counters *out);
+
+/* neighbourhood size N of every pixel (rpf.cpp:586: the neighbourhood vector's size) as the last pass of the most recent
+ * call left it: nbhd_out host, int32 [H*W] (rows outside the filtered slab: whatever an earlier call left there);
+ * count must equal desc W*H of that call.  For workload statistics (mean / percentiles of N). */
+int32_t rpf_query_nbhd(rpf_ctx *ctx, int32_t *nbhd_out, int64_t count);
 
 /* visualizeSF (rpf.cpp:37-101, visualization/vis.cpp:34-51): the reference's six debug images, without the EXR
  * writer: per-pixel mean over the S samples of n0, n1, p0, p1, (pFilm.x, pFilm.y, 0), (pLens.x, pLens.y, 0), each

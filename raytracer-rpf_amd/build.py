@@ -29,8 +29,11 @@ def _stale(target, deps):
     return (not os.path.exists(target)) or any(os.path.getmtime(f) > os.path.getmtime(target) for f in deps)
 
 
+SCAN_OK = os.path.join(OBJ_DIR, "spill_scan.ok")  # written by build() after scripts/check_spills.py passed
+
+
 def is_stale():
-    return _stale(LIB, SOURCES + HEADERS)
+    return _stale(LIB, SOURCES + HEADERS) or not os.path.exists(SCAN_OK)
 
 
 def build(force=False, verbose=False):
@@ -57,16 +60,28 @@ def build(force=False, verbose=False):
     import glob
     asm = sorted(f for f in glob.glob(os.path.join(OBJ_DIR, "*gfx950*.s")) if "rpf_api" not in os.path.basename(f))
     if asm:
-        chk = subprocess.run([sys.executable, os.path.join(_ROOT, "scripts", "check_spills.py")] + asm,
+        # the scan's verdict is kept next to the objects (is_stale() wants it) and, when every kernel TU was compiled in this
+        # invocation, the per-kernel resource usage of the build goes to profiles/ (tracked: the figures of what ships)
+        full = len(asm) == len(KERNEL_TUS)
+        report = os.path.join(_ROOT, "profiles", "r03_resource_usage.txt") if full else os.path.join(OBJ_DIR, "resource_usage_partial.txt")
+        chk = subprocess.run([sys.executable, os.path.join(_ROOT, "scripts", "check_spills.py"), "--report", report] + asm,
                              stdout=subprocess.PIPE, text=True)
         if chk.returncode != 0:
-            raise RuntimeError("miscompiled spill placement in the kernel TU (see scripts/check_spills.py):\n" + chk.stdout)
+            if os.path.exists(SCAN_OK):
+                os.remove(SCAN_OK)
+            for a in asm:  # the objects of a refused build must not be linked by a later invocation
+                o = os.path.join(OBJ_DIR, os.path.basename(a).split("-hip-amdgcn")[0] + ".hip.o")
+                if os.path.exists(o):
+                    os.remove(o)
+            raise RuntimeError("miscompiled spill placement in a kernel TU (see scripts/check_spills.py):\n" + chk.stdout)
+        with open(SCAN_OK, "w") as f:
+            f.write("check_spills.py: no spill code in front of an EXEC restore\n" + chk.stdout)
         if verbose:
             print(chk.stdout)
     for f in glob.glob(os.path.join(OBJ_DIR, "*")):  # the -save-temps intermediates (~100 MB) have served their purpose
-        if f not in objs:
+        if f not in objs and f != SCAN_OK and not (f.endswith(".txt") and "resolution" not in f):
             os.remove(f)
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

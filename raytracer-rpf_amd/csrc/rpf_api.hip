@@ -3,6 +3,7 @@
 // FillMeanAndStddev (stage 1a) then the fused filter; filtered colours replace the film's colours
 // (rpf.cpp:732) and feed the next pass.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <chrono>
 #include <climits>
@@ -42,6 +43,8 @@ struct rpf_ctx {
     uint64_t *d_masks = nullptr; size_t cap_masks = 0;     // size binning: stage-1b acceptance masks [H*W][stride]
     char *d_big_list = nullptr;  size_t cap_big_list = 0;  // streaming kernel: member lists [slots][nmax] u32
     char *d_big_bins = nullptr;  size_t cap_big_bins = 0;  //                   bin ids [slots][ndim][nmax] u8
+    uint32_t *d_redo_list = nullptr; size_t cap_redo = 0;  // REF_ABORT: pixels handed to the reference-expression kernel [H*W]
+    uint32_t *d_redo_count = nullptr;
     // membership depends on the features only, so within one call a pass with the same box and rows re-uses the
     // previous pass's masks and lists (reset at every API entry: the planes may change between calls)
     bool bin_valid = false;
@@ -59,6 +62,33 @@ struct rpf_ctx {
 };
 
 namespace {
+
+// Per-stage tracing hooks (the reference brackets its phases with ProfilePhase, core/stats.h:254): roctx ranges around the
+// host-side enqueue of upload / stage 1a / count + classify / each size-class launch / redo / reduce / download, visible in
+// `rocprofv3 --marker-trace --kernel-trace`.  The marker library is looked up at run time (the profiler preloads it; without
+// it, or without the library on the machine, the hooks are two null checks): librpf_hip.so has no link-time dependency on it.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char *lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void *h = dlopen(lib, RTLD_LAZY | RTLD_GLOBAL);
+            if (!h) continue;
+            push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+const Roctx &roctx() { static const Roctx r; return r; }
+struct Range {
+    bool on;
+    explicit Range(const char *name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~Range() { if (on) roctx().pop(); }
+    Range(const Range &) = delete;
+    Range &operator=(const Range &) = delete;
+};
 
 int32_t fail(rpf_ctx *c, int32_t st, const std::string &msg) {
     if (c) c->err = msg;
@@ -205,15 +235,44 @@ int32_t finish_counters(rpf_ctx *ctx, const rpf_desc *d, hipStream_t s);
 // (512 samples), the neighbourhood sizes are counted first and every kernel family filters its own pixel list with
 // LDS sized for its capacity (rpf_kernels.hip, "neighbourhood-size binning"); option "binning" = 0/1 overrides.
 // Needs stage 1a's planes (pmean / pstd) for those rows.  Synchronises the stream when it bins (list sizes).
-int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p, hipStream_t s, int *launches) {
+// REF_ABORT: the pixels the resident kernels appended to the redo list (an MI table inside the fixed-point rounding band at
+// a non-power-of-two N: the reference returns rounding residue there, rpf_filter_impl.inc stage 3b) are filtered again,
+// whole, by the streaming kernel, which evaluates the reference's floating-point expression for such tables.  The list
+// size stays on the device (no read-back): a fixed small grid whose workgroups find the list empty on ordinary frames.
+int32_t launch_redo(rpf_ctx *ctx, const PassParams &p, hipStream_t s, int *launches) {
+    if (p.redo_list == nullptr) return RPF_OK;
+    Range rg("rpf:redo (reference-expression kernel)");
+    PassParams q = p;
+    q.pix_list = p.redo_list;
+    q.list_count = 0;
+    const size_t per_slot = (size_t)q.nmax * (4 + (size_t)p.lay.ndim());
+    const uint32_t slots = (uint32_t)std::max<size_t>(8, std::min<size_t>(128, (64u << 20) / per_slot));
+    int32_t st;
+    if ((st = ensure(ctx, ctx->d_big_list, ctx->cap_big_list, (size_t)slots * q.nmax * 4))) return st;
+    if ((st = ensure(ctx, ctx->d_big_bins, ctx->cap_big_bins, (size_t)slots * q.nmax * p.lay.ndim()))) return st;
+    HIP_TRY(launch_filter_big(q, ctx->d_big_list, ctx->d_big_bins, slots, p.redo_count, s));
+    if (launches) ++*launches;
+    return RPF_OK;
+}
+
+int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p_in, hipStream_t s, int *launches) {
+    PassParams p = p_in;
+    p.redo_list = nullptr; p.redo_count = nullptr;
+    if (p.policy == RPF_DEGEN_REF_ABORT && !p.fast_weights && ctx->tun.stage_mask == -1) {
+        int32_t e;
+        if ((e = ensure(ctx, ctx->d_redo_list, ctx->cap_redo, (size_t)p.W * p.H * sizeof(uint32_t)))) return e;
+        HIP_TRY(hipMemsetAsync(ctx->d_redo_count, 0, sizeof(uint32_t), s));
+        p.redo_list = ctx->d_redo_list; p.redo_count = ctx->d_redo_count;
+    }
     bool bin = p.nmax > 512;
     if (ctx->tun.binning >= 0) bin = ctx->tun.binning != 0;
     if (p.nmax > kMaxResident) bin = true; // the streaming kernel takes the pixels no resident kernel can hold
     if (p.dbg.nbhd_size || p.dbg.mi) { /* debug planes are written by whichever launch owns the pixel: fine */ }
     if (!bin) {
+        Range rg("rpf:filter_pixel_kernel");
         HIP_TRY(launch_filter_pass(p, ctx->tun, s, nullptr));
         if (launches) ++*launches;
-        return RPF_OK;
+        return launch_redo(ctx, p, s, launches);
     }
     const size_t HW = (size_t)p.W * p.H;
     int32_t st;
@@ -234,6 +293,7 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p, hipStream_t s, i
     if (ctx->bin_valid && ctx->bin_box == p.box && ctx->bin_r0 == p.row_begin && ctx->bin_r1 == p.row_end) {
         std::memcpy(counts, ctx->bin_counts, sizeof(counts));
     } else {
+        Range rg("rpf:count + classify (stage 1b test, size classes)");
         ctx->bin_valid = false;
         HIP_TRY(hipMemsetAsync(ctx->d_class_counts, 0, kNumClasses * sizeof(uint32_t), s));
         HIP_TRY(launch_nbhd_count(pc, s));
@@ -250,6 +310,10 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p, hipStream_t s, i
     if ((int64_t)(p.box * p.box - 1) * p.S > 4096) tun.waves_per_pixel = 1;
     for (int c = 0; c < kNumClasses; ++c) {
         if (counts[c] == 0) continue;
+        static const char *const kClassName[kNumClasses] = {
+            "rpf:filter class N<=64", "rpf:filter class N<=128", "rpf:filter class N<=256", "rpf:filter class N<=448",
+            "rpf:filter class N<=832", "rpf:filter class N<=1600", "rpf:filter class N<=3136", "rpf:filter class streaming"};
+        Range rg(kClassName[c]);
         PassParams q = pc;
         q.nmax = std::min(p.nmax, class_capacity(c));
         q.bmax = std::max(1, (int)std::sqrt((double)q.nmax));
@@ -259,13 +323,13 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p, hipStream_t s, i
             const uint32_t slots = std::min<uint32_t>(counts[c], 1024u);
             if ((st = ensure(ctx, ctx->d_big_list, ctx->cap_big_list, (size_t)slots * q.nmax * 4))) return st;
             if ((st = ensure(ctx, ctx->d_big_bins, ctx->cap_big_bins, (size_t)slots * q.nmax * p.lay.ndim()))) return st;
-            HIP_TRY(launch_filter_big(q, ctx->d_big_list, ctx->d_big_bins, slots, s));
+            HIP_TRY(launch_filter_big(q, ctx->d_big_list, ctx->d_big_bins, slots, nullptr, s));
         } else {
             HIP_TRY(launch_filter_pass(q, tun, s, nullptr));
         }
         if (launches) ++*launches;
     }
-    return RPF_OK;
+    return launch_redo(ctx, pc, s, launches);
 }
 
 // runs all passes of desc on device-resident buffers; colour ends up in d_colour
@@ -293,7 +357,10 @@ int32_t run_passes(rpf_ctx *ctx, const rpf_desc *d, const void *d_planes, double
         HIP_TRY(launch_copy_colour_span(cin, cout, ps, (uint64_t)d->row_end * row, (uint64_t)(d->H - d->row_end) * row, s));
         if (timing) HIP_TRY(hipEventRecord(ctx->ev[1], s));
         // stage 1a depends on the features only: formed once (the reference recomputes identical values per pass)
-        if (i == 0) HIP_TRY(launch_pixel_stats(ps_.p, s));
+        if (i == 0) {
+            Range rg("rpf:stage 1a pixel_stats");
+            HIP_TRY(launch_pixel_stats(ps_.p, s));
+        }
         if (timing) HIP_TRY(hipEventRecord(ctx->ev[2], s));
         if ((st = launch_filter_binned(ctx, ps_.p, s, &c.filter_kernel_launches))) return st;
         if (timing) {
@@ -348,9 +415,13 @@ int32_t finish_counters(rpf_ctx *ctx, const rpf_desc *d, hipStream_t s) {
     HIP_TRY(launch_nbhd_reduce(ctx->d_nbhd, d->W, d->row_begin, d->row_end, ctx->d_nred, s));
     int32_t hst[2];
     unsigned long long nred[2];
+    uint32_t redo = 0;
     HIP_TRY(hipMemcpyAsync(hst, ctx->d_status, sizeof(hst), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(nred, ctx->d_nred, sizeof(nred), hipMemcpyDeviceToHost, s));
+    if (d->degenerate_policy == RPF_DEGEN_REF_ABORT)
+        HIP_TRY(hipMemcpyAsync(&redo, ctx->d_redo_count, sizeof(redo), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    c.redo_pixels = (int32_t)redo;
     c.samples_filtered = (int64_t)(d->row_end - d->row_begin) * d->W * d->S * d->n_box;
     c.options_active = ctx->tun.is_default() ? 0 : 1;
     c.sum_nbhd = (int64_t)nred[0];
@@ -423,6 +494,7 @@ int32_t run_host_pipeline(rpf_ctx *ctx, const rpf_desc *d, const void *planes_v,
         };
         auto emit_rows = [&](int j) -> int32_t { // last pass: reduce + download band j
             if (!want_out) return RPF_OK;
+            Range rg("rpf:reduce + download band");
             const Band &bd = bands[j];
             HIP_TRY(launch_reduce_rows(cout, ray_weight ? ctx->d_rayw : nullptr, sample_rgb_out ? ctx->d_srgb : nullptr,
                                        pixel_rgb_out ? ctx->d_prgb : nullptr, W, H, S, bd.r0, bd.r1, s));
@@ -444,6 +516,7 @@ int32_t run_host_pipeline(rpf_ctx *ctx, const rpf_desc *d, const void *planes_v,
             for (int j = 0; j < nb; ++j) {
                 const Band &bd = bands[j];
                 if (first) {
+                    Range rg("rpf:upload band + stage 1a");
                     const size_t o = (size_t)bd.r0 * row, n = (size_t)(bd.r1 - bd.r0) * row;
                     for (int k = 0; k < kNDim; ++k)
                         HIP_TRY(hipMemcpyAsync(ctx->d_planes + (k * ps + o) * pb, planes + (k * ps + o) * pb, n * pb,
@@ -514,6 +587,8 @@ int32_t rpf_create(rpf_ctx **out, int32_t device) {
     HIP_TRY(hipMalloc((void **)&ctx->d_status, 2 * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->d_nred, 2 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void **)&ctx->d_class_counts, kNumClasses * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->d_redo_count, sizeof(uint32_t)));
+    HIP_TRY(hipMemset(ctx->d_redo_count, 0, sizeof(uint32_t)));
     for (auto &e : ctx->ev) HIP_TRY(hipEventCreate(&e));
     return RPF_OK;
 }
@@ -524,7 +599,8 @@ void rpf_destroy(rpf_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *bufs[] = {ctx->d_planes, ctx->d_rayw, ctx->d_colA, ctx->d_colB, ctx->d_pmean, ctx->d_pstd, ctx->d_nbhd,
                     ctx->d_tfix, ctx->d_dfix, ctx->d_srgb, ctx->d_prgb, ctx->d_status, ctx->d_nred, ctx->d_lists,
-                    ctx->d_class_counts, ctx->d_masks, ctx->d_big_list, ctx->d_big_bins, ctx->d_carry};
+                    ctx->d_class_counts, ctx->d_masks, ctx->d_big_list, ctx->d_big_bins, ctx->d_carry, ctx->d_redo_list,
+                    ctx->d_redo_count};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (void *b : ctx->d_dbg)
@@ -653,11 +729,14 @@ int32_t rpf_filter_ex(rpf_ctx *ctx, const rpf_desc *d, const void *planes, const
         return run_host_pipeline(ctx, d, planes, ray_weight, sample_rgb_out, pixel_rgb_out);
     // serial variant (per-kernel event timing needs it): upload, passes, download
     const double t0 = now_ms();
-    HIP_TRY(hipMemcpyAsync(ctx->d_planes, planes, plane_total, hipMemcpyHostToDevice, s));
-    if (ray_weight) HIP_TRY(hipMemcpyAsync(ctx->d_rayw, ray_weight, ps * sizeof(float), hipMemcpyHostToDevice, s));
-    if (colour64_in) HIP_TRY(hipMemcpyAsync(ctx->d_colA, colour64_in, 3 * ps * sizeof(double), hipMemcpyHostToDevice, s));
-    else HIP_TRY(launch_colour_from_planes(ctx->d_planes, lay.f16 != 0, ctx->d_colA, ps, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    {
+        Range rg("rpf:upload");
+        HIP_TRY(hipMemcpyAsync(ctx->d_planes, planes, plane_total, hipMemcpyHostToDevice, s));
+        if (ray_weight) HIP_TRY(hipMemcpyAsync(ctx->d_rayw, ray_weight, ps * sizeof(float), hipMemcpyHostToDevice, s));
+        if (colour64_in) HIP_TRY(hipMemcpyAsync(ctx->d_colA, colour64_in, 3 * ps * sizeof(double), hipMemcpyHostToDevice, s));
+        else HIP_TRY(launch_colour_from_planes(ctx->d_planes, lay.f16 != 0, ctx->d_colA, ps, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     const double t1 = now_ms();
     const int32_t fst = run_passes(ctx, d, ctx->d_planes, ctx->d_colA, s);
     if (fst != RPF_OK && fst != RPF_E_NONFINITE) return fst;
@@ -667,6 +746,7 @@ int32_t rpf_filter_ex(rpf_ctx *ctx, const rpf_desc *d, const void *planes, const
         HIP_TRY(hipStreamSynchronize(s));
     }
     if (sample_rgb_out || pixel_rgb_out) {
+        Range rg("rpf:reduce + download");
         HIP_TRY(launch_reduce(ctx->d_colA, ray_weight ? ctx->d_rayw : nullptr, sample_rgb_out ? ctx->d_srgb : nullptr,
                               pixel_rgb_out ? ctx->d_prgb : nullptr, d->W, d->H, d->S, s));
         if (sample_rgb_out)
@@ -770,11 +850,15 @@ int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *d, int32_t box, cons
         if (host_dbg[i]) HIP_TRY(hipMemcpyAsync(host_dbg[i], ctx->d_dbg[i], dbg_bytes[i], hipMemcpyDeviceToHost, s));
     int32_t hst[2];
     unsigned long long nred[2];
+    uint32_t redo = 0;
     HIP_TRY(hipMemcpyAsync(hst, ctx->d_status, sizeof(hst), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(nred, ctx->d_nred, sizeof(nred), hipMemcpyDeviceToHost, s));
+    if (d->degenerate_policy == RPF_DEGEN_REF_ABORT)
+        HIP_TRY(hipMemcpyAsync(&redo, ctx->d_redo_count, sizeof(redo), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     rpf_counters &c = ctx->counters;
     c = rpf_counters{};
+    c.redo_pixels = (int32_t)redo;
     c.samples_filtered = (int64_t)(d->row_end - d->row_begin) * d->W * d->S;
     c.options_active = ctx->tun.is_default() ? 0 : 1;
     c.sum_nbhd = (int64_t)nred[0];
@@ -823,6 +907,16 @@ int32_t rpf_selftest_udiv(rpf_ctx *ctx, uint64_t n, uint64_t seed, int32_t mode,
 int32_t rpf_query_counters(rpf_ctx *ctx, rpf_counters *out) {
     if (!ctx || !out) return RPF_E_BADARG;
     *out = ctx->counters;
+    return RPF_OK;
+}
+
+int32_t rpf_query_nbhd(rpf_ctx *ctx, int32_t *nbhd_out, int64_t count) {
+    if (!ctx) return RPF_E_BADARG;
+    if (!nbhd_out || count <= 0) return fail(ctx, RPF_E_BADARG, "nbhd_out is NULL or count <= 0");
+    if (!ctx->d_nbhd || (size_t)count * sizeof(int32_t) > ctx->cap_nbhd)
+        return fail(ctx, RPF_E_BADARG, "no neighbourhood plane of that size: run a filter call first (count = W*H)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy(nbhd_out, ctx->d_nbhd, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost));
     return RPF_OK;
 }
 
@@ -989,6 +1083,7 @@ int32_t rpf_multi_filter(rpf_multi *m, const rpf_desc *d, const void *planes_v, 
         const int box = d->box_sizes[i];
         // ---- colour halo refresh from the neighbours' owned rows (pass 0: the upload already carried it) ----------
         if (i > 0 && G > 1) {
+            Range rg("rpf:colour halo refresh (peer copies)");
             for (int g = 0; g + 1 < G; ++g) {
                 rpf_ctx *up = m->ctx[g], *dn = m->ctx[g + 1];
                 const size_t ps_u = row * sl[g].rows(), ps_d = row * sl[g + 1].rows();
@@ -1086,6 +1181,7 @@ int32_t rpf_multi_filter(rpf_multi *m, const rpf_desc *d, const void *planes_v, 
         tot.nonfinite_pixels += c.nonfinite_pixels;
         tot.max_nbhd = std::max(tot.max_nbhd, c.max_nbhd);
         tot.options_active |= c.options_active;
+        tot.redo_pixels += c.redo_pixels;
         if (c.first_bad_pixel >= 0) { // slab-local y*W+x -> image index
             const int yl = c.first_bad_pixel / W, x = c.first_bad_pixel % W;
             const int gi = (sl[g].a - sl[g].ht + yl) * W + x;

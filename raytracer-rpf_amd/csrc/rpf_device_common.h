@@ -10,6 +10,7 @@
 
 #include "rpf_internal.h"
 #include "rpf_xlane.h"
+#include "rpf_reflog.h"
 
 namespace rpf {
 

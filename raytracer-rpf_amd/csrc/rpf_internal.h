@@ -52,6 +52,8 @@ struct PassParams {
     uint32_t list_count;
     uint64_t *masks;       // size-binned launch: acceptance masks of stage 1b, [H*W][mask_stride] (one per 64 candidates,
     uint32_t mask_stride;  //   written by nbhd_count_kernel, re-used by the filter kernels), or null
+    uint32_t *redo_list;   // REF_ABORT: pixels whose MI stage met a table inside the rounding band at a non-power-of-two N are
+    uint32_t *redo_count;  //   appended here and filtered again by filter_pixel_big_kernel (reference expression); or null
     int32_t *status;       // [0] count of NaN pixels, [1] lowest bad pixel index (atomicMin)
     rpf_debug dbg;         // device pointers, any may be null
 };
@@ -95,7 +97,8 @@ int class_capacity(int c);          // 64, 128, 256, 448, 832, 1600, 3136, 65535
 hipError_t launch_nbhd_count(const PassParams &p, hipStream_t s);
 // the streaming kernel (neighbourhoods of the last size class): global scratch of `slots` workgroups,
 // list [slots][nmax] u32 and bins [slots][ndim][nmax] u8
-hipError_t launch_filter_big(const PassParams &p, void *list, void *bins, uint32_t slots, hipStream_t s);
+// count_dev != null: the size of p.pix_list is read from device memory (redo mode: no host read-back), grid = slots
+hipError_t launch_filter_big(const PassParams &p, void *list, void *bins, uint32_t slots, const uint32_t *count_dev, hipStream_t s);
 hipError_t launch_classify(const PassParams &p, uint32_t *lists /*[7][H*W]*/, uint32_t *counts /*[7], zeroed*/, hipStream_t s);
 hipError_t launch_colour_from_planes(const void *planes, bool f16, double *colour, uint64_t plane_stride, hipStream_t s);
 hipError_t launch_colour_from_planes_span(const void *planes, bool f16, double *colour, uint64_t plane_stride, uint64_t e0,

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void nbhd_reduce_kernel(const int32_t *nbhd, u
     hipError_t impl_filter_large(const PassParams &p, const LdsLayout &L, const LdsLayout &L2, const LdsLayout &L3, bool t_in_lds, unsigned grid, hipStream_t s); \
     hipError_t impl_pixel_stats(const PassParams &p, uint64_t pix0, uint64_t pix1, hipStream_t s);                        \
     hipError_t impl_nbhd_count(const PassParams &p, unsigned grid, hipStream_t s);                                        \
-    hipError_t impl_filter_big(const PassParams &p, void *list, void *bins, uint32_t slots, hipStream_t s);               \
+    hipError_t impl_filter_big(const PassParams &p, void *list, void *bins, uint32_t slots, const uint32_t *count_dev, hipStream_t s);               \
     }
 RPF_DECLARE_IMPL(d19) // the reference's 19 dims (2 random parameters, 12 features), fp32 planes
 RPF_DECLARE_IMPL(d27) // BASELINE configs[4]: 27 dims (4 random parameters, 18 features), fp16 feature storage
@@ -371,9 +371,9 @@ hipError_t launch_nbhd_count(const PassParams &p, hipStream_t s) {
     return p.lay.is_ref19() ? d19::impl_nbhd_count(p, grid, s) : d27::impl_nbhd_count(p, grid, s);
 }
 
-hipError_t launch_filter_big(const PassParams &p, void *list, void *bins, uint32_t slots, hipStream_t s) {
-    if (!p.lay.supported() || p.masks == nullptr || p.pix_list == nullptr) return hipErrorInvalidValue;
-    return p.lay.is_ref19() ? d19::impl_filter_big(p, list, bins, slots, s) : d27::impl_filter_big(p, list, bins, slots, s);
+hipError_t launch_filter_big(const PassParams &p, void *list, void *bins, uint32_t slots, const uint32_t *count_dev, hipStream_t s) {
+    if (!p.lay.supported() || p.pix_list == nullptr) return hipErrorInvalidValue;
+    return p.lay.is_ref19() ? d19::impl_filter_big(p, list, bins, slots, count_dev, s) : d27::impl_filter_big(p, list, bins, slots, count_dev, s);
 }
 
 hipError_t launch_classify(const PassParams &p, uint32_t *lists, uint32_t *counts, hipStream_t s) {

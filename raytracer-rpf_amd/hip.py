@@ -29,7 +29,7 @@ EXPORTS = ["rpf_version", "rpf_status_string", "rpf_create", "rpf_destroy", "rpf
            "rpf_filter_pass_debug", "rpf_query_counters", "rpf_lds_bytes_required", "rpf_selftest_udiv", "rpf_feature_images",
            "rpf_host_alloc", "rpf_host_free", "rpf_filter_ex", "rpf_set_option", "rpf_multi_create", "rpf_multi_destroy",
            "rpf_multi_last_error", "rpf_multi_device_count", "rpf_multi_set_option", "rpf_multi_filter",
-           "rpf_multi_query_counters"]
+           "rpf_multi_query_counters", "rpf_query_nbhd"]
 
 
 class Desc(C.Structure):
@@ -56,7 +56,8 @@ class Counters(C.Structure):
     _fields_ = [("samples_filtered", C.c_int64), ("sum_nbhd", C.c_int64), ("nonfinite_pixels", C.c_int64),
                 ("max_nbhd", C.c_int32), ("first_bad_pixel", C.c_int32), ("filter_kernel_ms", C.c_float),
                 ("stats_kernel_ms", C.c_float), ("device_total_ms", C.c_float), ("h2d_ms", C.c_float),
-                ("d2h_ms", C.c_float), ("filter_kernel_launches", C.c_int32), ("options_active", C.c_int32)]
+                ("d2h_ms", C.c_float), ("filter_kernel_launches", C.c_int32), ("options_active", C.c_int32),
+                ("redo_pixels", C.c_int32)]
 
 
 class RpfError(RuntimeError):
@@ -101,6 +102,7 @@ def load():
         L.rpf_filter_pass_debug.argtypes = [C.c_void_p, C.POINTER(Desc), C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.POINTER(Debug)]
         L.rpf_query_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+        L.rpf_query_nbhd.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.rpf_selftest_udiv.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_uint64)]
         L.rpf_feature_images.argtypes = [C.c_void_p, C.POINTER(Desc), C.c_void_p, C.c_void_p]
         L.rpf_lds_bytes_required.restype = C.c_int64
@@ -183,6 +185,12 @@ class Context:
         c = Counters()
         self._check(self._L.rpf_query_counters(self._h, C.byref(c)))
         return c
+
+    def nbhd(self, W, H):
+        """neighbourhood size of every pixel as the last pass of the most recent call left it (rpf_query_nbhd)"""
+        out = np.empty((H, W), np.int32)
+        self._check(self._L.rpf_query_nbhd(self._h, _p(out), W * H))
+        return out
 
     # ---- host-buffer entry points ------------------------------------------------------------------
     def host_empty(self, shape, dtype=np.float32):

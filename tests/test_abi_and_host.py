@@ -32,8 +32,8 @@ def test_struct_layouts_match_header(hipmod):
     # rpf_desc: 5 + 1 + 8 + 3 int32 = 17 int32 -> 68 bytes, padded to 72, + 2 doubles = 88, + 4 int32 (layout) = 104
     assert C.sizeof(hipmod.Desc) == 104 and hipmod.Desc.eps.offset == 72 and hipmod.Desc.n_random.offset == 88
     assert C.sizeof(hipmod.Debug) == 9 * C.sizeof(C.c_void_p)
-    assert C.sizeof(hipmod.Counters) == 3 * 8 + 2 * 4 + 5 * 4 + 2 * 4 + 4 and hipmod.Counters.filter_kernel_ms.offset == 32
-    assert hipmod.Counters.options_active.offset == 56
+    assert C.sizeof(hipmod.Counters) == 3 * 8 + 2 * 4 + 5 * 4 + 3 * 4 and hipmod.Counters.filter_kernel_ms.offset == 32
+    assert hipmod.Counters.options_active.offset == 56 and hipmod.Counters.redo_pixels.offset == 60
 
 
 def test_no_device_means_loud_failure_not_fallback(hipmod):

@@ -150,38 +150,93 @@ def test_config4_shape_full_rank_slab_3840x276x32(ctx, hipmod, oracle):
     assert rel_l2(out[:, r0:r0 + 1].cpu().numpy(), want) <= REL_L2_BAR
 
 
-def test_exactly_independent_table_at_non_power_of_two_n(ctx, hipmod, oracle):
-    """One pixel, S = N = 15, B = 3: columns binned (5,5,5) against columns binned (9,3,3) are EXACTLY independent
-    (J_ij * 15 == hx_i * hy_j).  For N a power of two mi.cpp returns an exact 0 for such a table; at N = 15 its quotients
-    pXY / (pX * pY) round to 1 +- 2.2e-16 and it returns rounding residue instead.  Recorded behaviour:
-      REF_ABORT  oracle (= the reference statement by statement): |MI| ~ 1e-17 residue feeds rpf.cpp:465/470, the
-                 weights are arbitrary; the HIP path evaluates MI over integers and returns exactly 0 for the same
-                 pairs (documented deviation, DESIGN.md section 5) -- everything discrete is identical;
-      EPS        both sides return exactly 0 (the residue contract) and every weight agrees to rounding."""
-    W, H, S = 1, 1, 15
-    a = np.repeat([0.0, 0.5, 1.0], 5)                                   # bins (5,5,5)
-    b = np.concatenate([np.tile([0.0] * 3 + [0.5] + [1.0], 3)])         # bins (9,3,3), independent of a
-    rng = np.random.default_rng(3)
-    planes = np.empty((19, H, W, S), np.float32)
-    for c in range(19):
-        planes[c, 0, 0] = rng.permutation(15) / 14.0                    # generic columns
-    planes[5, 0, 0], planes[6, 0, 0] = a, b                             # r0, r1
-    planes[7, 0, 0], planes[8, 0, 0] = b, a                             # f0, f1
-    pa, pb = oracle.pair_table()
-    ref = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7))
-    got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S), box=7, allow_nonfinite=True)
-    indep = [i for i in range(96) if (pa[i], pb[i]) in ((7, 5), (8, 6))]
-    assert len(indep) == 2
-    assert (np.abs(ref["mi"][0, 0, indep]) < 1e-15).all() and (got["mi"][0, 0, indep] == 0).all()
+def _independent_columns(n, bins):
+    """two columns of n values whose `bins`-bin histograms are EXACTLY independent: a has n/bins samples per bin; inside
+    every a-bin one sample sits in each of b's higher bins and the rest in b's first: J_ij * n == hx_i * hy_j on every cell"""
+    blk = n // bins
+    vals = np.arange(bins) / (bins - 1.0)
+    a = np.repeat(vals, blk)
+    per = [blk - (bins - 1)] + [1] * (bins - 1)
+    b = np.tile(np.repeat(vals, per), bins)
+    return a, b
+
+
+def _assert_ref_abort_parity(got, ref, hipmod, indep):
+    """REF_ABORT parity on a frame with in-band MI tables: identical status / NaN pattern, identical zero / non-zero
+    pattern AND bits of the in-band MI values, every stage output of check_pass where the colours are finite"""
+    assert (got["status"] == hipmod.E_NONFINITE) == (ref["status"] == 1)
+    assert got["nonfinite_pixels"] == ref["nonfinite_pixels"] and got["first_bad_pixel"] == ref["first_bad_pixel"]
+    gi, ri = got["mi"][..., indep], ref["mi"][..., indep]
+    assert np.array_equal(gi == 0, ri == 0)
+    assert np.array_equal(gi, ri)              # the reference's own residue, bit for bit (rpf_reflog.h)
+    assert np.array_equal(np.isnan(got["colour"]), np.isnan(ref["colour"]))
     for k in ("nbhd_size", "member_hash", "bin_hash"):
         assert (got[k] == ref[k]).all()
     assert np.array_equal(got["mean"], ref["mean"]) and np.array_equal(got["stddev"], ref["stddev"])
-    others = [i for i in range(96) if i not in indep]
-    np.testing.assert_allclose(got["mi"][0, 0, others], ref["mi"][0, 0, others], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(got["mi"], ref["mi"], rtol=0, atol=1e-11)
+    for k in ("alpha", "beta", "wrc"):        # the weights are quotients OF residues: equal MI bits give equal weights
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-12, equal_nan=True)
+    fin = np.isfinite(ref["colour"])
+    assert rel_l2(got["colour"][fin], ref["colour"][fin]) <= REL_L2_BAR
+
+
+@pytest.mark.parametrize("S,bins", [(15, 3), (12, 3), (24, 4)])
+def test_exactly_independent_table_at_non_power_of_two_n(ctx, hipmod, oracle, S, bins):
+    """One pixel, N = S not a power of two, B = floor(sqrt(N)): two column pairs whose joint histograms are EXACTLY
+    independent (J_ij * N == hx_i * hy_j).  For N a power of two mi.cpp returns an exact 0 for such a table; otherwise its
+    quotients pXY / (pX * pY) round to 1 +- 2.2e-16 and it returns rounding residue, which rpf.cpp:465/470 then divide by
+    each other.  REF_ABORT promises the reference's value: the resident kernel hands such a pixel to
+    filter_pixel_big_kernel, which evaluates mi.cpp:66-86 term by term (round 2 returned 0 here and recorded the
+    deviation).  EPS: both sides return exactly 0 (the residue contract).  S = 24 takes the size-binned route."""
+    W, H = 1, 1
+    assert int(np.sqrt(S)) == bins
+    a, b = _independent_columns(S, bins)
+    rng = np.random.default_rng(3)
+    planes = np.empty((19, H, W, S), np.float32)
+    for c in range(19):
+        planes[c, 0, 0] = rng.permutation(S) / (S - 1.0)                # generic columns
+    planes[5, 0, 0], planes[6, 0, 0] = a, b                             # r0, r1
+    planes[7, 0, 0], planes[8, 0, 0] = b, a                             # f0, f1
+    pa, pb = oracle.pair_table()
+    indep = [i for i in range(96) if (pa[i], pb[i]) in ((7, 5), (8, 6))]
+    assert len(indep) == 2
+    ref = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7))
+    got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S), box=7, allow_nonfinite=True)
+    assert (np.abs(ref["mi"][0, 0, indep]) < 1e-15).all()
+    assert ctx.counters().redo_pixels == 1
+    _assert_ref_abort_parity(got, ref, hipmod, indep)
     e_ref = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7, policy=oracle.DEGEN_EPS))
     e_got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS), box=7)
     assert (e_ref["mi"][0, 0, indep] == 0).all() and (e_got["mi"][0, 0, indep] == 0).all()
+    assert ctx.counters().redo_pixels == 0
     check_pass(e_got, e_ref)
+
+
+def test_independent_tables_in_every_size_class_ref_abort(ctx, hipmod, oracle):
+    """An 11x11 frame at 15 spp, box 9, in which EVERY pixel's neighbourhood holds an exactly independent (f0, r0) table at
+    a non-power-of-two N: each pixel carries a three-valued column a (5, 5, 5) against a column b with (3, 1, 1) samples per
+    a-value, and every other feature is a permutation of the same 15 values in every pixel (same mean and sigma: all
+    neighbours pass the 3-sigma test), so a window is a union of whole pixels -- N = 15 * (25 ... 81) = 375 ... 1215: the
+    one-wave K = 7 and K = 13 classes and the split route (chains / bins + MI / weights) of the K = 25 class all meet the
+    redo path, and pX = 1/3 against pY = 3/5 makes the reference's quotients inexact (real residue).  The whole frame must
+    equal the oracle under REF_ABORT: status, NaN pattern, residue bits, weights, colours."""
+    W, H, S, box = 11, 11, 15, 9
+    rng = np.random.default_rng(17)
+    planes = rng.permuted(np.broadcast_to(np.linspace(0.4, 0.6, S), (19, H, W, S)), axis=3).astype(np.float32)
+    planes[0] = (np.arange(W)[None, :, None] + rng.random((H, W, S))).astype(np.float32)
+    planes[1] = (np.arange(H)[:, None, None] + rng.random((H, W, S))).astype(np.float32)
+    a, b = _independent_columns(S, 3)
+    planes[5], planes[7] = a.astype(np.float32), b.astype(np.float32)   # r0, f0: the same pattern in every pixel
+    pa, pb = oracle.pair_table()
+    indep = [i for i in range(96) if (pa[i], pb[i]) == (7, 5)]
+    ref = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=box))
+    got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S), box=box, allow_nonfinite=True)
+    n = ref["nbhd_size"]
+    assert n.min() == 25 * S and n.max() == 81 * S and (n == 81 * S).sum() == 9      # whole-pixel windows
+    ri = ref["mi"][..., indep]
+    assert (np.abs(ri) < 1e-14).all() and (ri != 0).sum() > 20                        # residue, not zeros
+    assert ctx.counters().redo_pixels == int(((n & (n - 1)) != 0).sum()) == W * H
+    _assert_ref_abort_parity(got, ref, hipmod, indep)
 
 
 @pytest.mark.parametrize("W,H,S,box,mode,sf,sc", [
@@ -276,7 +331,8 @@ def test_multi_pass_and_pixel_reduction(ctx, hipmod, oracle):
     want_pix = oracle.pixel_mean(c, oracle.make_desc(W, H, S), rw)
     assert rel_l2(prgb.astype(np.float64), want_pix) <= REL_L2_BAR
     cnt = ctx.counters()
-    assert cnt.samples_filtered == W * H * S * 2 and cnt.filter_kernel_launches == 2
+    # per pass: the fused kernel + (REF_ABORT) the reference-expression kernel over the redo list, which is empty here
+    assert cnt.samples_filtered == W * H * S * 2 and cnt.filter_kernel_launches == 4 and cnt.redo_pixels == 0
 
 
 def test_multi_pass_with_size_binning(ctx, hipmod, oracle):

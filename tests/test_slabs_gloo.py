@@ -84,3 +84,21 @@ def test_partition_arithmetic():
     with pytest.raises(ValueError):
         slabs.slab_for(40, 8, 3, 27)   # box 55 needs 27 halo rows, 40/8 = 5 rows per rank
     assert slabs.slab_for(40, 1, 0, 27) == slabs.Slab(0, 40, 0, 0)
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must spawn its ranks itself (a child
+    torch.distributed.run, before anything touches a GPU) and print rank 0's one JSON line; --rendezvous-only stops after
+    the gloo rendezvous + an all-reduce so the launcher path runs here, without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                        "--rendezvous-only"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rendezvous"] == "ok" and d["sum_of_ranks_plus_one"] == 3.0
