@@ -172,6 +172,9 @@ int32_t rpf_filter_ex(rpf_ctx *ctx, const rpf_desc *desc, const void *planes, co
  *                      kernel, the light stages at two to three times the occupancy: -1 auto (default: on), 0 off, 1 on;
  *                      same results bit for bit
  *   "strip_w"          pixels per XCD strip of the pixel walk: 0 auto (default), else a multiple of 8; same results
+ *   "packed"           neighbourhoods of N <= 64 samples on the packed kernels (8 / 4 / 2 / 1 pixels per wavefront): -1 auto
+ *                      (default: on), 0 off (every pixel gets a whole wavefront), 1 on.  Every stage output up to alpha / beta /
+ *                      W_r_c is the same bits either way; colours agree to rounding (~1e-16 relative)
  *   "screen"           far-pair screen of the weight stage (four-wave kernels): 1 on (default), 0 off.  Both settings
  *                      give the same filtered colours bit for bit.
  * rpf_counters.options_active tells whether a result was produced under any override. */

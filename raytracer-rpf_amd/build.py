@@ -14,7 +14,8 @@ LIB = os.path.join(_HERE, "lib", "librpf_hip.so")
 KERNEL_TUS = ["rpf_impl_%s_%s.hip" % (lay, part) for lay in ("d19", "d27") for part in ("small", "mid", "large")] + ["rpf_kernels.hip"]
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in KERNEL_TUS + ["rpf_api.hip"]]
 HEADERS = [os.path.join(_HERE, "csrc", "rpf_internal.h"), os.path.join(_HERE, "csrc", "rpf_xlane.h"),
-           os.path.join(_HERE, "csrc", "rpf_filter_impl.inc"), os.path.join(_HERE, "csrc", "rpf_device_common.h"),
+           os.path.join(_HERE, "csrc", "rpf_filter_impl.inc"), os.path.join(_HERE, "csrc", "rpf_packed_impl.inc"),
+           os.path.join(_HERE, "csrc", "rpf_device_common.h"), os.path.join(_HERE, "csrc", "rpf_reflog.h"),
            os.path.join(_ROOT, "include", "rpf_hip.h")]
 
 

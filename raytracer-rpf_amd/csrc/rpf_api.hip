@@ -49,7 +49,7 @@ struct rpf_ctx {
     // previous pass's masks and lists (reset at every API entry: the planes may change between calls)
     bool bin_valid = false;
     int bin_box = 0, bin_r0 = 0, bin_r1 = 0;
-    uint32_t bin_counts[kNumClasses] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t bin_counts[kNumClasses] = {};
     // debug planes
     void *d_dbg[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_dbg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -268,14 +268,44 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p_in, hipStream_t s
     if (ctx->tun.binning >= 0) bin = ctx->tun.binning != 0;
     if (p.nmax > kMaxResident) bin = true; // the streaming kernel takes the pixels no resident kernel can hold
     if (p.dbg.nbhd_size || p.dbg.mi) { /* debug planes are written by whichever launch owns the pixel: fine */ }
-    if (!bin) {
-        Range rg("rpf:filter_pixel_kernel");
-        HIP_TRY(launch_filter_pass(p, ctx->tun, s, nullptr));
-        if (launches) ++*launches;
-        return launch_redo(ctx, p, s, launches);
-    }
+    // small neighbourhoods (N <= 64) run on the packed kernels, several pixels per wave (rpf_packed_impl.inc); option "packed"
+    const bool packed = ctx->tun.packed != 0 && !p.fast_weights && ctx->tun.stage_mask == -1 && ctx->tun.lds_pad == 0;
     const size_t HW = (size_t)p.W * p.H;
     int32_t st;
+    if (!bin) {
+        PassParams q = p;
+        if (packed) {
+            // the fused kernel finds N itself (stage 1b); a pixel with N <= 64 leaves its acceptance masks, joins the list of
+            // its lane class and exits; the four packed launches read their list sizes on the device (no host read-back)
+            q.mask_stride = (uint32_t)std::max<int64_t>(1, ((int64_t)(p.box * p.box - 1) * p.S + 63) / 64);
+            if ((st = ensure(ctx, ctx->d_lists, ctx->cap_lists, (size_t)kNumClasses * HW * sizeof(uint32_t)))) return st;
+            if ((st = ensure(ctx, ctx->d_masks, ctx->cap_masks, HW * q.mask_stride * sizeof(uint64_t)))) return st;
+            HIP_TRY(hipMemsetAsync(ctx->d_class_counts, 0, kNumClasses * sizeof(uint32_t), s));
+            q.reroute_masks = ctx->d_masks;
+        }
+        {
+            Range rg("rpf:filter_pixel_kernel");
+            HIP_TRY(launch_filter_pass(q, ctx->tun, s, nullptr));
+            if (launches) ++*launches;
+        }
+        if (packed) {
+            Range rg("rpf:packed kernels (N <= 8, 16, 32, 64)");
+            HIP_TRY(launch_classify(q, ctx->d_lists, ctx->d_class_counts, kNumPacked, s));
+            for (int c = 0; c < kNumPacked; ++c) {
+                if (p.S > class_capacity(c)) continue; // N >= S: the list is empty by construction
+                PassParams r = q;
+                r.reroute_masks = nullptr;
+                r.masks = ctx->d_masks;
+                r.nmax = std::min(p.nmax, class_capacity(c));
+                r.bmax = std::max(1, (int)std::sqrt((double)r.nmax));
+                r.pix_list = ctx->d_lists + (size_t)c * HW;
+                r.list_count = (uint32_t)((size_t)(p.row_end - p.row_begin) * p.W); // upper bound: sizes the grid
+                HIP_TRY(launch_filter_packed(r, class_capacity(c), ctx->d_class_counts + c, s));
+                if (launches) ++*launches;
+            }
+        }
+        return launch_redo(ctx, p, s, launches);
+    }
     if ((st = ensure(ctx, ctx->d_lists, ctx->cap_lists, (size_t)kNumClasses * HW * sizeof(uint32_t)))) return st;
     // the count pass keeps its acceptance masks (one u64 per 64 candidates) so the filter kernels only rebuild the list
     PassParams pc = p;
@@ -297,7 +327,7 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p_in, hipStream_t s
         ctx->bin_valid = false;
         HIP_TRY(hipMemsetAsync(ctx->d_class_counts, 0, kNumClasses * sizeof(uint32_t), s));
         HIP_TRY(launch_nbhd_count(pc, s));
-        HIP_TRY(launch_classify(pc, ctx->d_lists, ctx->d_class_counts, s));
+        HIP_TRY(launch_classify(pc, ctx->d_lists, ctx->d_class_counts, kNumClasses, s));
         HIP_TRY(hipMemcpyAsync(counts, ctx->d_class_counts, sizeof(counts), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         std::memcpy(ctx->bin_counts, counts, sizeof(counts));
@@ -311,7 +341,8 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p_in, hipStream_t s
     for (int c = 0; c < kNumClasses; ++c) {
         if (counts[c] == 0) continue;
         static const char *const kClassName[kNumClasses] = {
-            "rpf:filter class N<=64", "rpf:filter class N<=128", "rpf:filter class N<=256", "rpf:filter class N<=448",
+            "rpf:filter class N<=8", "rpf:filter class N<=16", "rpf:filter class N<=32", "rpf:filter class N<=64",
+            "rpf:filter class N<=128", "rpf:filter class N<=256", "rpf:filter class N<=448",
             "rpf:filter class N<=832", "rpf:filter class N<=1600", "rpf:filter class N<=3136", "rpf:filter class streaming"};
         Range rg(kClassName[c]);
         PassParams q = pc;
@@ -324,6 +355,8 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p_in, hipStream_t s
             if ((st = ensure(ctx, ctx->d_big_list, ctx->cap_big_list, (size_t)slots * q.nmax * 4))) return st;
             if ((st = ensure(ctx, ctx->d_big_bins, ctx->cap_big_bins, (size_t)slots * q.nmax * p.lay.ndim()))) return st;
             HIP_TRY(launch_filter_big(q, ctx->d_big_list, ctx->d_big_bins, slots, nullptr, s));
+        } else if (c < kNumPacked && packed) {
+            HIP_TRY(launch_filter_packed(q, class_capacity(c), nullptr, s));
         } else {
             HIP_TRY(launch_filter_pass(q, tun, s, nullptr));
         }
@@ -689,6 +722,7 @@ int32_t rpf_set_option(rpf_ctx *ctx, const char *name, int64_t value) {
     else if (n == "screen" && value >= 0 && value <= 1) t.screen = (int32_t)value;
     else if (n == "split_weights" && value >= -1 && value <= 1) t.split_weights = (int32_t)value;
     else if (n == "strip_w" && value >= 0 && value <= 4096 && value % 8 == 0) t.strip_w = (int32_t)value;
+    else if (n == "packed" && value >= -1 && value <= 1) t.packed = (int32_t)value;
     else if (n == "lds_pad" && value >= 0 && value <= 160 * 1024) t.lds_pad = (int32_t)value;
     else return fail(ctx, RPF_E_BADARG, "unknown option or value out of range: " + n);
     ctx->bin_valid = false;

@@ -52,6 +52,10 @@ struct PassParams {
     uint32_t list_count;
     uint64_t *masks;       // size-binned launch: acceptance masks of stage 1b, [H*W][mask_stride] (one per 64 candidates,
     uint32_t mask_stride;  //   written by nbhd_count_kernel, re-used by the filter kernels), or null
+    // unbinned route (box*box*S <= 512): filter_pixel_kernel leaves the pixels whose neighbourhood turns out small (N <= 64) to
+    // the packed kernels -- it writes its acceptance masks and N and exits; classify_kernel then deals those pixels into the
+    // lane-class lists (one atomic per wave and class: a per-pixel append on one counter cost 11 ns per pixel, 22 ms a frame)
+    uint64_t *reroute_masks;   // [H*W][mask_stride], or null = no re-routing
     uint32_t *redo_list;   // REF_ABORT: pixels whose MI stage met a table inside the rounding band at a non-power-of-two N are
     uint32_t *redo_count;  //   appended here and filtered again by filter_pixel_big_kernel (reference expression); or null
     int32_t *status;       // [0] count of NaN pixels, [1] lowest bad pixel index (atomicMin)
@@ -70,7 +74,8 @@ struct Tuning {
     int32_t screen = 1;          // far-pair screen (stage 4, four-wave kernels): 0 off, 1 on; same results
     int32_t split_weights = -1;  // 32- / 64-spp classes as three kernels (chains; bins + MI; weights): -1 auto (on), 0 off, 1 on; same results
     int32_t strip_w = 0;         // pixels per XCD strip of the pixel walk: 0 auto (by box and spp), else a multiple of 8; same results
-    bool is_default() const { return waves_per_pixel == 0 && table_in_lds == -1 && lds_pad == 0 && binning == -1 && stage_mask == -1 && screen == 1 && strip_w == 0 && split_weights == -1; }
+    int32_t packed = -1;         // small neighbourhoods (N <= 64) on the packed kernels, several pixels per wave: -1 auto (on), 0 off, 1 on
+    bool is_default() const { return waves_per_pixel == 0 && table_in_lds == -1 && lds_pad == 0 && binning == -1 && stage_mask == -1 && screen == 1 && strip_w == 0 && split_weights == -1 && packed == -1; }
 };
 
 struct LdsLayout {
@@ -90,16 +95,23 @@ hipError_t launch_pixel_stats(const PassParams &p, hipStream_t s);
 hipError_t launch_pixel_stats_rows(const PassParams &p, int r0, int r1, hipStream_t s);
 hipError_t launch_filter_pass(const PassParams &p, const Tuning &tun, hipStream_t s, uint32_t *lds_bytes_out);
 // neighbourhood-size binning (large box*box*S): count N per pixel, then deal the pixels into one list per kernel family
-constexpr int kNumClasses = 8;      // seven LDS-resident kernel families + the streaming kernel for larger neighbourhoods
+constexpr int kNumPacked = 4;       // lane classes of the packed kernels: N <= 8, 16, 32, 64 (8, 4, 2, 1 pixels per wave)
+constexpr int kNumClasses = 11;     // four packed lane classes (one-wave K = 1 kernel when the packed route is off), six more
+                                    // LDS-resident kernel families, the streaming kernel for larger neighbourhoods
 constexpr int kMaxResident = 3136;  // largest neighbourhood the LDS-resident kernels hold (64 lanes x 49 samples)
 constexpr int kMaxNbhd = 65535;     // the streaming kernel: 16-bit histogram cells, one-byte bin ids
-int class_capacity(int c);          // 64, 128, 256, 448, 832, 1600, 3136, 65535
+int class_capacity(int c);          // 8, 16, 32, 64, 128, 256, 448, 832, 1600, 3136, 65535
+// the packed kernels (rpf_packed_impl.inc): pixels of p.pix_list with N <= lanes_per_pixel; count_dev != null: the list size
+// is read on the device and p.list_count is only its upper bound
+hipError_t launch_filter_packed(const PassParams &p, int lanes_per_pixel, const uint32_t *count_dev, hipStream_t s);
 hipError_t launch_nbhd_count(const PassParams &p, hipStream_t s);
 // the streaming kernel (neighbourhoods of the last size class): global scratch of `slots` workgroups,
 // list [slots][nmax] u32 and bins [slots][ndim][nmax] u8
 // count_dev != null: the size of p.pix_list is read from device memory (redo mode: no host read-back), grid = slots
 hipError_t launch_filter_big(const PassParams &p, void *list, void *bins, uint32_t slots, const uint32_t *count_dev, hipStream_t s);
-hipError_t launch_classify(const PassParams &p, uint32_t *lists /*[7][H*W]*/, uint32_t *counts /*[7], zeroed*/, hipStream_t s);
+// max_class < kNumClasses: pixels of that class and above are left out (the unbinned route lists the packed classes only)
+hipError_t launch_classify(const PassParams &p, uint32_t *lists /*[kNumClasses][H*W]*/, uint32_t *counts /*[kNumClasses], zeroed*/,
+                           int max_class, hipStream_t s);
 hipError_t launch_colour_from_planes(const void *planes, bool f16, double *colour, uint64_t plane_stride, hipStream_t s);
 hipError_t launch_colour_from_planes_span(const void *planes, bool f16, double *colour, uint64_t plane_stride, uint64_t e0,
                                           uint64_t cnt, hipStream_t s);

@@ -38,7 +38,7 @@ struct ClassCaps { int cap[kNumClasses]; };
 
 // pixels in slab_pixel order -> one list per class (class = first capacity >= N); lists[c][*], counts[c]
 __global__ __launch_bounds__(256) void classify_kernel(PassParams p, ClassCaps caps, uint32_t *lists, uint32_t *counts,
-                                                       uint64_t list_stride) {
+                                                       uint64_t list_stride, int max_class) {
     const int lane = threadIdx.x & (kWave - 1);
     const int rows_band = (p.row_end - p.row_begin + 7) / 8;
     const int64_t per_band = (int64_t)rows_band * p.W;
@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void classify_kernel(PassParams p, ClassCaps c
 #pragma unroll
         for (int c = kNumClasses - 2; c >= 0; --c)
             if (n <= caps.cap[c]) cls = c;
+        if (cls >= max_class) cls = -1;
     }
 #pragma unroll
     for (int c = 0; c < kNumClasses; ++c) {
@@ -195,7 +196,8 @@ __global__ __launch_bounds__(256) void nbhd_reduce_kernel(const int32_t *nbhd, u
     hipError_t impl_filter_large(const PassParams &p, const LdsLayout &L, const LdsLayout &L2, const LdsLayout &L3, bool t_in_lds, unsigned grid, hipStream_t s); \
     hipError_t impl_pixel_stats(const PassParams &p, uint64_t pix0, uint64_t pix1, hipStream_t s);                        \
     hipError_t impl_nbhd_count(const PassParams &p, unsigned grid, hipStream_t s);                                        \
-    hipError_t impl_filter_big(const PassParams &p, void *list, void *bins, uint32_t slots, const uint32_t *count_dev, hipStream_t s);               \
+    hipError_t impl_filter_big(const PassParams &p, void *list, void *bins, uint32_t slots, const uint32_t *count_dev, hipStream_t s); \
+    hipError_t impl_filter_packed(const PassParams &p, int lanes_per_pixel, const uint32_t *count_dev, hipStream_t s);    \
     }
 RPF_DECLARE_IMPL(d19) // the reference's 19 dims (2 random parameters, 12 features), fp32 planes
 RPF_DECLARE_IMPL(d27) // BASELINE configs[4]: 27 dims (4 random parameters, 18 features), fp16 feature storage
@@ -360,7 +362,7 @@ hipError_t launch_filter_pass(const PassParams &p, const Tuning &tun, hipStream_
 }
 
 int class_capacity(int c) {
-    static const int caps[kNumClasses] = {64, 128, 256, 448, 832, 1600, 3136, kMaxNbhd}; // 64 * {1, 2, 4, 7, 13, 25, 49}, streaming
+    static const int caps[kNumClasses] = {8, 16, 32, 64, 128, 256, 448, 832, 1600, 3136, kMaxNbhd}; // packed lane classes; 64 * {2, 4, 7, 13, 25, 49}; streaming
     return caps[c];
 }
 
@@ -371,18 +373,23 @@ hipError_t launch_nbhd_count(const PassParams &p, hipStream_t s) {
     return p.lay.is_ref19() ? d19::impl_nbhd_count(p, grid, s) : d27::impl_nbhd_count(p, grid, s);
 }
 
+hipError_t launch_filter_packed(const PassParams &p, int lanes_per_pixel, const uint32_t *count_dev, hipStream_t s) {
+    if (!p.lay.supported()) return hipErrorNotSupported;
+    return p.lay.is_ref19() ? d19::impl_filter_packed(p, lanes_per_pixel, count_dev, s) : d27::impl_filter_packed(p, lanes_per_pixel, count_dev, s);
+}
+
 hipError_t launch_filter_big(const PassParams &p, void *list, void *bins, uint32_t slots, const uint32_t *count_dev, hipStream_t s) {
     if (!p.lay.supported() || p.pix_list == nullptr) return hipErrorInvalidValue;
     return p.lay.is_ref19() ? d19::impl_filter_big(p, list, bins, slots, count_dev, s) : d27::impl_filter_big(p, list, bins, slots, count_dev, s);
 }
 
-hipError_t launch_classify(const PassParams &p, uint32_t *lists, uint32_t *counts, hipStream_t s) {
+hipError_t launch_classify(const PassParams &p, uint32_t *lists, uint32_t *counts, int max_class, hipStream_t s) {
     const int64_t total = (int64_t)((p.row_end - p.row_begin + 7) / 8) * p.W * 8;
     if (total <= 0) return hipSuccess;
     ClassCaps caps;
     for (int c = 0; c < kNumClasses; ++c) caps.cap[c] = class_capacity(c);
     hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, caps, lists, counts,
-                       (uint64_t)p.H * p.W);
+                       (uint64_t)p.H * p.W, max_class);
     return hipGetLastError();
 }
 

@@ -97,7 +97,7 @@ def _gauss(xp, idx, seed, stream):
 
 
 def synth_planes(W, H, S, seed=20250103, sigma_f=0.05, sigma_c=1e-4, row0=0, xp=None, lens_colour=True,
-                 mode="smooth", n_random=2, n_feat=12, dtype="f32"):
+                 mode="smooth", n_random=2, n_feat=12, dtype="f32", flat_frac=0.0):
     """Synthetic feature buffer, planes [5 + n_random + n_feat, H, W, S] (SURVEY.md section 8d recipe); fp32, or fp16
     with dtype="f16" (BASELINE configs[4]: fp16 feature storage).  The defaults give the reference's 19 dims.  Wider
     layouts append: random parameters r3, r4, ... (further sample dimensions, e.g. the light sample) and features
@@ -115,6 +115,11 @@ def synth_planes(W, H, S, seed=20250103, sigma_f=0.05, sigma_c=1e-4, row0=0, xp=
     the colour is a mode value plus noise sigma_c.  Same-mode samples are near-identical in normalised
     space, so the cross-bilateral weights are non-trivial and the filter measurably changes the colours:
     the parity-fixture workload.
+    ``flat_frac`` > 0: that fraction of the pixels (chosen by a hash of the pixel index) are "flat quads": their first-hit
+    normal is the same three values in all S samples, the smooth field at the pixel centre.  A zero-variance feature is what
+    93.9 % of the pixels of a captured pbrt buffer have, and it makes the strict 3-sigma test reject every
+    neighbour (|f - m| >= 0 always): N = S exactly for those pixels -- the stand-in for a path-traced buffer (needs the
+    EPS policy, as the captured buffers do: the reference aborts on them).
     """
     xp = xp or _NP
     n = H * W * S
@@ -187,6 +192,17 @@ def synth_planes(W, H, S, seed=20250103, sigma_f=0.05, sigma_c=1e-4, row0=0, xp=
         cb = alb[2] * vis * shade + sigma_c * G(32)
     elif mode != "smooth":
         raise ValueError("mode must be 'smooth' or 'clustered'")
+
+    if flat_frac > 0.0:
+        pidx = py * W + px  # global pixel index: slab independent
+        flat = _uniform(xp, pidx, seed, 77) < flat_frac
+        Xc, Yc = (xp.cast(px, xp.f64) + 0.5) * 0.01, (xp.cast(py, xp.f64) + 0.5) * 0.01
+        if mode == "clustered":
+            fnx, fny, fnz = 0.3 + 0.0 * Xc, -0.2 + 0.0 * Xc, 0.6 + 0.02 * xp.sin(Xc * 2.0 + Yc)
+        else:
+            fnx, fny = 0.35 * xp.sin(3.0 * Xc), 0.35 * xp.cos(2.0 * Yc)
+            fnz = math.sqrt(1.0 - 0.35 * 0.35 * 2.0 * 0.5) + 0.05 * xp.sin(Xc + Yc)
+        nx, ny, nz = xp.where(flat, fnx, nx), xp.where(flat, fny, ny), xp.where(flat, fnz, nz)
 
     rand = [r1, r2] + [U(5 + k) for k in range(n_random - 2)]
     feats = [nx, ny, nz, p0x, p0y, p0z, n1x, n1y, n1z, p1x, p1y, p1z]

@@ -93,6 +93,9 @@ def demangle_short(name):
     s = (ns.group(1) + "::" if ns else "") + (base.group(1) if base else name[:60])
     if k:
         s += "<K=%s,TL=%s,FAST=%s,NW=%s,PHASE=%s>" % k.groups()
+    g = re.search(r"packed_kernelILi(\d+)E", name)
+    if g:
+        s += "<G=%s>" % g.group(1)
     return s
 
 

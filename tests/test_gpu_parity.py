@@ -293,6 +293,66 @@ def test_ref_abort_status_on_constant_feature(ctx, hipmod, oracle):
     assert np.isfinite(got["colour"]).all()
 
 
+@pytest.mark.parametrize("W,H,S,box,sf,flat,policy", [
+    (40, 24, 8, 7, 1e-5, 0.0, 1),    # N = 8 ... 40: 8 / 4 / 2 / 1 pixels per wave, unbinned route (re-routed by the fused kernel)
+    (40, 24, 8, 7, 3e-3, 0.0, 1),    # N up to ~100: some pixels stay on the one-wave kernels, the small ones are re-routed
+    (40, 24, 8, 7, 0.05, 0.94, 1),   # the captured-buffer regime: 94 % flat-quad pixels with N = S = 8, the rest large
+    (33, 17, 4, 7, 1e-5, 0.0, 1),    # S = 4: N = 4 ... 18; B = 2 at N < 9
+    (30, 14, 16, 7, 1e-5, 0.0, 1),   # 16 spp: size-binned route, lists from classify_kernel; N = 18 ... 73
+    (24, 10, 32, 5, 1e-5, 0.7, 1),   # 32 spp, box 5: two pixels per wave (N = 32) and one
+    (12, 8, 64, 5, 1e-6, 0.7, 1),    # 64 spp: N = 64 exactly -> one pixel per wave on the packed kernel (G = 64)
+    (21, 13, 1, 7, 0.05, 0.0, 1),    # one sample per pixel: sigma = 0, N = 1, B = 1
+    (40, 24, 8, 7, 1e-5, 0.0, 0),    # REF_ABORT on a buffer that completes
+    (40, 24, 8, 7, 0.05, 0.94, 0),   # REF_ABORT on the captured-buffer regime: the reference aborts; same NaN pattern
+])
+def test_packed_small_neighbourhood_kernels(ctx, hipmod, oracle, W, H, S, box, sf, flat, policy):
+    """N <= 64: the packed kernels (several pixels per wavefront, popcount histograms; rpf_packed_impl.inc) against the
+    oracle AND against the one-wave-per-pixel kernels (option "packed" = 0): every stage output up to alpha / beta / W_r_c
+    the same bits on both routes, colours to rounding."""
+    planes = fb.synth_planes(W, H, S, seed=21, sigma_f=sf, sigma_c=0.01, mode="smooth", flat_frac=flat)
+    desc = hipmod.make_desc(W, H, S, policy=policy)
+    got = ctx.filter_pass_debug(planes, desc, box=box, allow_nonfinite=True)
+    want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=box, policy=policy))
+    small = int((want["nbhd_size"] <= 64).sum())
+    assert small > 0.2 * W * H                      # the packed kernels really ran on a good share of the frame
+    assert (got["status"] == hipmod.E_NONFINITE) == (want["status"] == 1)
+    assert np.array_equal(np.isnan(got["colour"]), np.isnan(want["colour"]))
+    assert got["nonfinite_pixels"] == want["nonfinite_pixels"] and got["first_bad_pixel"] == want["first_bad_pixel"]
+    if np.isfinite(want["colour"]).all():
+        check_pass(got, want)
+    with hipmod.Context(0) as c2:
+        c2.set_option("packed", 0)
+        old = c2.filter_pass_debug(planes, desc, box=box, allow_nonfinite=True)
+    for k in ("nbhd_size", "member_hash", "bin_hash", "mean", "stddev", "mi", "alpha", "beta", "wrc"):
+        assert np.array_equal(got[k], old[k], equal_nan=True), k
+    assert got["status"] == old["status"] and got["nonfinite_pixels"] == old["nonfinite_pixels"]
+    assert np.array_equal(np.isnan(got["colour"]), np.isnan(old["colour"]))
+    m = np.isfinite(old["colour"])
+    np.testing.assert_allclose(got["colour"][m], old["colour"][m], rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.parametrize("S", [8, 16])
+def test_flat_quad_shortcut_and_nan_candidates(ctx, hipmod, oracle, S):
+    """Stage 1b's flat-quad shortcut: a pixel with a zero-variance feature rejects every finite candidate (3 sigma = 0, strict
+    test), proven from the stage-1a means of the window's pixels instead of testing its samples.  The one candidate that
+    passes such a feature is a NaN one (NaN >= 0 is false): a window that holds a NaN sample must take the general test
+    and accept it exactly as the reference does.  Membership (size, order) against the oracle on both the unbinned (8 spp)
+    and the size-binned (16 spp) route."""
+    W, H = 26, 15
+    planes = fb.synth_planes(W, H, S, seed=5, sigma_f=0.05, sigma_c=0.01, mode="smooth", flat_frac=0.8)
+    planes[7:10, 7, 11, 3] = np.nan     # one sample with a NaN normal (all three flat features) in the middle of the frame
+    planes[9, 3, 20, 0] = np.nan        # and one with a single NaN component (still rejected by the other two flat features)
+    want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7, policy=oracle.DEGEN_EPS))
+    got = ctx.filter_pass_debug(planes, hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS), box=7, allow_nonfinite=True)
+    n = want["nbhd_size"]
+    assert (n == S).mean() > 0.5 and (n > S).sum() > 10
+    assert (n[4:11, 8:15] == S + 1).sum() > 5   # the NaN sample was accepted into flat pixels' neighbourhoods
+    assert np.array_equal(got["nbhd_size"], n) and np.array_equal(got["member_hash"], want["member_hash"])
+    assert np.array_equal(np.isnan(got["colour"]), np.isnan(want["colour"]))
+    m = np.isfinite(want["colour"])
+    assert rel_l2(got["colour"][m], want["colour"][m]) <= REL_L2_BAR
+
+
 @pytest.mark.parametrize("beta_map", [0, 1, 2])
 def test_beta_numerator_presets(ctx, hipmod, oracle, beta_map):
     W, H, S = 16, 12, 8
@@ -331,8 +391,9 @@ def test_multi_pass_and_pixel_reduction(ctx, hipmod, oracle):
     want_pix = oracle.pixel_mean(c, oracle.make_desc(W, H, S), rw)
     assert rel_l2(prgb.astype(np.float64), want_pix) <= REL_L2_BAR
     cnt = ctx.counters()
-    # per pass: the fused kernel + (REF_ABORT) the reference-expression kernel over the redo list, which is empty here
-    assert cnt.samples_filtered == W * H * S * 2 and cnt.filter_kernel_launches == 4 and cnt.redo_pixels == 0
+    # per pass: the fused kernel + the four packed launches over the re-routed small pixels (list sizes stay on the device)
+    # + (REF_ABORT) the reference-expression kernel over the redo list, which is empty here
+    assert cnt.samples_filtered == W * H * S * 2 and cnt.filter_kernel_launches == 2 * (1 + 4 + 1) and cnt.redo_pixels == 0
 
 
 def test_multi_pass_with_size_binning(ctx, hipmod, oracle):
