@@ -17,8 +17,9 @@ synthetic feature buffer that is already resident in HBM.
     slab per rank generated on the device in row chunks (the full 8192^2 frame is 232 GB of features); 66 algorithmic
     bytes per sample (27 x fp16 read + 3 x fp32 written).
 --workload cfg1: BASELINE configs[0]'s shape, 400x400x8 spp, one pass, EPS policy, on the stand-in for a captured pbrt buffer
-    (pbrt cannot be built here): the seeded generator with an in-pixel jitter so small that the 3-sigma test rejects nearly
-    every neighbour (N = S for most pixels); cpu_baseline = the oracle on the FULL frame.
+    (pbrt cannot be built here): the seeded generator with 94 % flat-quad pixels (a zero-variance normal: the strict 3-sigma
+    test rejects every neighbour, N = S) and a 1e-5 in-pixel jitter elsewhere -- mean N ~ 9, p99 ~ 26, as SURVEY F10 measured on
+    a captured killeroo buffer; cpu_baseline = the oracle on the FULL frame.
 --workload cfg3: BASELINE configs[2]'s shape, 1920x1080x16 spp, four passes {7,7,5,5} per step, EPS policy, same
     small-neighbourhood generator; `value` counts every pass (W*H*S*4 samples per step).
 Run without torch.distributed.run and --gpus N > 1, the script starts the N ranks itself (a child torch.distributed.run,
@@ -41,7 +42,9 @@ for _p in (ROOT, os.path.join(ROOT, "oracle")):
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 SMOOTH = dict(mode="smooth", sigma_f=0.05, sigma_c=1e-4)   # large neighbourhoods (mean N ~ 0.75 box^2 S): the throughput workload
-SMALLN = dict(mode="smooth", sigma_f=1e-5, sigma_c=1e-4)   # in-pixel jitter 1e-5: N = S ... 2S, what captured pbrt buffers look like
+# the stand-in for a captured pbrt buffer (93.9 % of the pixels have a zero-variance feature => N = S; mean N 9.8,
+# p99 26): 94 % flat-quad pixels, the others with an in-pixel jitter of 1e-5 (N = S ... 4S)
+SMALLN = dict(mode="smooth", sigma_f=1e-5, sigma_c=1e-4, flat_frac=0.94)
 WORKLOADS = {
     # name: width, rows per GPU, spp, layout kwargs, algorithmic bytes per sample per pass,
     #       generator, box list of one step, degenerate policy
@@ -93,7 +96,12 @@ def spawn_ranks(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    # only rank 0's JSON line goes to stdout (gloo's C++ side prints its "[Gloo] Rank ..." banner there too)
+    pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in pr.stdout:
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return pr.wait()
 
 
 def rendezvous_only(args):
@@ -338,8 +346,8 @@ def main():
     algo_bytes = wl["algo_bytes"] * n_own * W * S * n_pass
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     gen = wl["gen"]
-    workload = "synthetic %dx%dx%dspp (%s, sigma_f=%g), %s, %s" % (
-        W, rows_per_gpu, S, gen["mode"], gen["sigma_f"],
+    workload = "synthetic %dx%dx%dspp (%s, sigma_f=%g%s), %s, %s" % (
+        W, rows_per_gpu, S, gen["mode"], gen["sigma_f"], ", flat_frac=%g" % gen["flat_frac"] if gen.get("flat_frac") else "",
         "box %d, 1 pass" % box if n_pass == 1 else "%d passes %s per step" % (n_pass, "{%s}" % ",".join(map(str, boxes))), wl["label"])
     out = {
         "metric": "RPF Msamples/sec filtered at 1080p×8spp",

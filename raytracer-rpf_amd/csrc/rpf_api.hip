@@ -43,10 +43,13 @@ struct rpf_ctx {
     uint64_t *d_masks = nullptr; size_t cap_masks = 0;     // size binning: stage-1b acceptance masks [H*W][stride]
     char *d_big_list = nullptr;  size_t cap_big_list = 0;  // streaming kernel: member lists [slots][nmax] u32
     char *d_big_bins = nullptr;  size_t cap_big_bins = 0;  //                   bin ids [slots][ndim][nmax] u8
+    uint8_t *d_flat = nullptr;   size_t cap_flat = 0;      // stage 1a by-product: pixels with a zero-variance feature [H*W]
+    int32_t *d_nan_flag = nullptr;                         // ... and whether any feature mean of the buffer is NaN
     uint32_t *d_redo_list = nullptr; size_t cap_redo = 0;  // REF_ABORT: pixels handed to the reference-expression kernel [H*W]
     uint32_t *d_redo_count = nullptr;
     // membership depends on the features only, so within one call a pass with the same box and rows re-uses the
     // previous pass's masks and lists (reset at every API entry: the planes may change between calls)
+    bool flat_fresh = false;   // d_flat / d_nan_flag describe the planes of the call in progress (stage 1a ran in it)
     bool bin_valid = false;
     int bin_box = 0, bin_r0 = 0, bin_r1 = 0;
     uint32_t bin_counts[kNumClasses] = {};
@@ -219,6 +222,8 @@ int32_t setup_pass(rpf_ctx *ctx, const rpf_desc *d, int box, const void *d_plane
     if ((st = ensure_tables(ctx, p.nmax))) return st;
     p.pmean = ctx->d_pmean; p.pstd = ctx->d_pstd; p.tfix = ctx->d_tfix; p.dfix = ctx->d_dfix;
     p.nbhd = ctx->d_nbhd; p.status = ctx->d_status;
+    if ((st = ensure(ctx, ctx->d_flat, ctx->cap_flat, HW))) return st;
+    p.flat = ctx->d_flat; p.nan_flag = ctx->d_nan_flag;
     if (dbg_dev) p.dbg = *dbg_dev;
     {   // LDS of the largest resident kernel this pass can launch (larger neighbourhoods stream: filter_pixel_big_kernel)
         const int nres = std::min(p.nmax, kMaxResident), bres = std::max(1, (int)std::sqrt((double)nres));
@@ -283,11 +288,28 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p_in, hipStream_t s
             HIP_TRY(hipMemsetAsync(ctx->d_class_counts, 0, kNumClasses * sizeof(uint32_t), s));
             q.reroute_masks = ctx->d_masks;
         }
-        {
+        bool run_main = true;
+        if (packed && ctx->flat_fresh) {
+            // pixels that stage 1a proved flat (a zero-variance feature, no NaN mean in the buffer: N = S) never reach the fused
+            // kernel: the others are listed in slab order (the list of the streaming class is free on this route) and the fused
+            // kernel walks that list.  One 4-byte read-back per pass: a one-wave workgroup per flat pixel that only finds out it has
+            // nothing to do cost 5.8 ms per 1080p frame of a captured-like buffer.
+            Range rg("rpf:prelist (flat quads)");
+            uint32_t *glist = ctx->d_lists + (size_t)(kNumClasses - 1) * HW, *gcount = ctx->d_class_counts + (kNumClasses - 1);
+            HIP_TRY(launch_prelist(q, glist, gcount, s));
+            uint32_t n_general = 0;
+            HIP_TRY(hipMemcpyAsync(&n_general, gcount, sizeof(n_general), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            const uint32_t npix = (uint32_t)((size_t)(p.row_end - p.row_begin) * p.W);
+            if (n_general == 0) run_main = false;
+            else if (n_general < npix) { q.pix_list = glist; q.list_count = n_general; }
+        }
+        if (run_main) {
             Range rg("rpf:filter_pixel_kernel");
             HIP_TRY(launch_filter_pass(q, ctx->tun, s, nullptr));
             if (launches) ++*launches;
         }
+        q.pix_list = nullptr; q.list_count = 0;
         if (packed) {
             Range rg("rpf:packed kernels (N <= 8, 16, 32, 64)");
             HIP_TRY(launch_classify(q, ctx->d_lists, ctx->d_class_counts, kNumPacked, s));
@@ -375,6 +397,8 @@ int32_t run_passes(rpf_ctx *ctx, const rpf_desc *d, const void *d_planes, double
     const int32_t init_status[2] = {0, INT_MAX};
     HIP_TRY(hipMemcpyAsync(ctx->d_status, init_status, sizeof(init_status), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(ctx->d_nred, 0, 2 * sizeof(unsigned long long), s));
+    HIP_TRY(hipMemsetAsync(ctx->d_nan_flag, 0, sizeof(int32_t), s)); // stage 1a (pass 0) refills it, and the flat plane
+    ctx->flat_fresh = true;
     rpf_counters &c = ctx->counters;
     c = rpf_counters{};
     c.first_bad_pixel = -1;
@@ -497,6 +521,8 @@ int32_t run_host_pipeline(rpf_ctx *ctx, const rpf_desc *d, const void *planes_v,
     const int32_t init_status[2] = {0, INT_MAX};
     HIP_TRY(hipMemcpyAsync(ctx->d_status, init_status, sizeof(init_status), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(ctx->d_nred, 0, 2 * sizeof(unsigned long long), s));
+    HIP_TRY(hipMemsetAsync(ctx->d_nan_flag, 0, sizeof(int32_t), s));
+    ctx->flat_fresh = true;
     rpf_counters &c = ctx->counters;
     c = rpf_counters{};
     c.first_bad_pixel = -1;
@@ -620,6 +646,8 @@ int32_t rpf_create(rpf_ctx **out, int32_t device) {
     HIP_TRY(hipMalloc((void **)&ctx->d_status, 2 * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->d_nred, 2 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void **)&ctx->d_class_counts, kNumClasses * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->d_nan_flag, sizeof(int32_t)));
+    HIP_TRY(hipMemset(ctx->d_nan_flag, 0, sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->d_redo_count, sizeof(uint32_t)));
     HIP_TRY(hipMemset(ctx->d_redo_count, 0, sizeof(uint32_t)));
     for (auto &e : ctx->ev) HIP_TRY(hipEventCreate(&e));
@@ -633,7 +661,7 @@ void rpf_destroy(rpf_ctx *ctx) {
     void *bufs[] = {ctx->d_planes, ctx->d_rayw, ctx->d_colA, ctx->d_colB, ctx->d_pmean, ctx->d_pstd, ctx->d_nbhd,
                     ctx->d_tfix, ctx->d_dfix, ctx->d_srgb, ctx->d_prgb, ctx->d_status, ctx->d_nred, ctx->d_lists,
                     ctx->d_class_counts, ctx->d_masks, ctx->d_big_list, ctx->d_big_bins, ctx->d_carry, ctx->d_redo_list,
-                    ctx->d_redo_count};
+                    ctx->d_redo_count, ctx->d_flat, ctx->d_nan_flag};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (void *b : ctx->d_dbg)
@@ -870,6 +898,8 @@ int32_t rpf_filter_pass_debug(rpf_ctx *ctx, const rpf_desc *d, int32_t box, cons
     if ((st = setup_pass(ctx, d, box, ctx->d_planes, ctx->d_colA, ctx->d_colB, &dev, ps_))) return st;
     HIP_TRY(launch_copy_f64(ctx->d_colA, ctx->d_colB, 3 * ps, s));
     const bool timing = (d->flags & RPF_FLAG_TIMING) != 0;
+    HIP_TRY(hipMemsetAsync(ctx->d_nan_flag, 0, sizeof(int32_t), s));
+    ctx->flat_fresh = true;
     HIP_TRY(launch_pixel_stats(ps_.p, s));
     if (timing) HIP_TRY(hipEventRecord(ctx->ev[0], s));
     int n_launch = 0;
@@ -1103,7 +1133,9 @@ int32_t rpf_multi_filter(rpf_multi *m, const rpf_desc *d, const void *planes_v, 
         HIP_TRY(launch_colour_from_planes(ctx->d_planes, lay.f16 != 0, ctx->d_colA, ps, s));
         const int32_t init_status[2] = {0, INT_MAX};
         HIP_TRY(hipMemcpyAsync(ctx->d_status, init_status, sizeof(init_status), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(ctx->d_nan_flag, 0, sizeof(int32_t), s));
         HIP_TRY(hipStreamSynchronize(s));
+        ctx->flat_fresh = true;
         ctx->bin_valid = false;
         ctx->counters = rpf_counters{};
         cin[g] = ctx->d_colA; cout[g] = ctx->d_colB;

@@ -56,6 +56,11 @@ struct PassParams {
     // the packed kernels -- it writes its acceptance masks and N and exits; classify_kernel then deals those pixels into the
     // lane-class lists (one atomic per wave and class: a per-pixel append on one counter cost 11 ns per pixel, 22 ms a frame)
     uint64_t *reroute_masks;   // [H*W][mask_stride], or null = no re-routing
+    // stage 1a's by-product: flat[pix] = 1 when some feature of the pixel has sigma == 0 (and a finite mean) -- the strict 3-sigma
+    // test then rejects every finite candidate (flat_quad_shortcut) -- and *nan_flag != 0 when any feature mean of the buffer is
+    // NaN (the one kind of candidate that would still pass).  flat && !*nan_flag proves N = S without touching a sample.
+    uint8_t *flat;         // [H*W], or null
+    int32_t *nan_flag;     // [1]
     uint32_t *redo_list;   // REF_ABORT: pixels whose MI stage met a table inside the rounding band at a non-power-of-two N are
     uint32_t *redo_count;  //   appended here and filtered again by filter_pixel_big_kernel (reference expression); or null
     int32_t *status;       // [0] count of NaN pixels, [1] lowest bad pixel index (atomicMin)
@@ -122,6 +127,9 @@ hipError_t launch_reduce_rows(const double *colour, const float *ray_weight, flo
                               int H, int S, int r0, int r1, hipStream_t s);
 hipError_t launch_reduce(const double *colour, const float *ray_weight, float *sample_rgb, float *pixel_rgb, int W,
                          int H, int S, hipStream_t s);
+// unbinned route: deals the pixels of the slab (slab_pixel order) into the list of those that need the fused kernel's own
+// stage 1b; a proven flat pixel gets nbhd = S instead (the packed kernels take it from there)
+hipError_t launch_prelist(const PassParams &p, uint32_t *list, uint32_t *count /* zeroed */, hipStream_t s);
 hipError_t launch_nbhd_reduce(const int32_t *nbhd, int W, int row_begin, int row_end, unsigned long long *out2,
                               hipStream_t s);
 hipError_t launch_feature_images(const float *planes, int W, int H, int S, double *out, unsigned long long *maxbits, hipStream_t s);

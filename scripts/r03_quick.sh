@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r03q
 python -m pytest tests -m gpu -q -x -k "packed or flat_quad or config1 or small_neigh or independent" > gpurun_out/r03q/tests.log 2>&1; tail -3 gpurun_out/r03q/tests.log
-for c in 0 2; do
+for c in ${CASES:-0 2 3}; do
   CASE=$c PACKED=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03q/trace_$c -- python3 scripts/smalln.py > gpurun_out/r03q/trace_$c.log 2>&1
   grep kernel_ms gpurun_out/r03q/trace_$c.log | cut -c1-420
   f=$(find gpurun_out/r03q/trace_$c -name "*kernel_stats.csv" | head -1)
