@@ -235,7 +235,11 @@ int32_t rpf_selftest_udiv(rpf_ctx *ctx, uint64_t n, uint64_t seed, int32_t mode,
  * the image into contiguous row slabs (rows [g*H/G, (g+1)*H/G) on entry g), uploads each slab with the halo rows of its
  * neighbours ((box-1)/2 rows, rpf.cpp:561-571), runs every pass on all slabs concurrently, and refreshes the colour
  * halo between passes with peer-to-peer copies of the neighbour's owned boundary rows (features never change, so their
- * halo travels with the upload).  Results are bit-identical to rpf_filter() on one device.  desc->row_begin / row_end
+ * halo travels with the upload).  Results are bit-identical to rpf_filter() on one device -- VERIFIED with two and three slab
+ * contexts on ONE device (plain device copies for the halo); the branch taken between two different ordinals
+ * (hipDeviceEnablePeerAccess + hipMemcpyPeerAsync) has not executed on hardware in this repository's development (one-GPU
+ * boxes): tests/test_gpu_parity.py::test_multi_context_row_slabs_equal_one_context carries (0, 1) cases that run wherever a
+ * second GPU is visible, and bench.py's `multi_inprocess` leg uses every visible device.  desc->row_begin / row_end
  * must name the whole image; a slab must own at least (box-1)/2 rows.  One caller thread per rpf_multi. */
 typedef struct rpf_multi rpf_multi;
 int32_t rpf_multi_create(rpf_multi **out, const int32_t *devices, int32_t n_devices);

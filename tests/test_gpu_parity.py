@@ -522,6 +522,29 @@ def test_far_pair_screen_changes_nothing(ctx, hipmod, S, mode, layout):
     assert on["nonfinite_pixels"] == off["nonfinite_pixels"]
 
 
+def test_far_pair_screen_keeps_nonfinite_colours(ctx, hipmod, oracle):
+    """A neighbour whose colour is inf poisons every sum it enters, even with weight 0.0 (0 x inf = NaN, rpf.cpp:692; the
+    reference then exits at rpf.cpp:702).  The far-pair screen must not skip such a sample: the same NaN pixels with the
+    screen on and off, and the oracle's count."""
+    W, H, S = 12, 9, 32
+    planes = fb.synth_planes(W, H, S, seed=89, sigma_f=0.05, sigma_c=1e-3, mode="smooth")
+    cin = planes[2:5].astype(np.float64)
+    cin[1, 4, 6, 5] = np.inf
+    desc = hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS)
+    on = ctx.filter_pass_debug(planes, desc, box=7, colour_in=cin, debug=False)
+    ctx.set_option("screen", 0)
+    try:
+        off = ctx.filter_pass_debug(planes, desc, box=7, colour_in=cin, debug=False)
+    finally:
+        ctx.set_option("screen", 1)
+    want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=7, policy=oracle.DEGEN_EPS), colour_in=cin, debug=False)
+    assert on["max_nbhd"] > 832 and want["nonfinite_pixels"] > 10
+    assert on["nonfinite_pixels"] == off["nonfinite_pixels"] == want["nonfinite_pixels"]
+    assert np.array_equal(on["colour"], off["colour"], equal_nan=True)
+    m = np.isfinite(want["colour"])
+    assert np.array_equal(np.isfinite(on["colour"]), m) and rel_l2(on["colour"][m], want["colour"][m]) <= REL_L2_BAR
+
+
 @pytest.mark.parametrize("S,layout", [(64, 19), (64, 27), (32, 19), (32, 27)])
 def test_split_weight_kernel_changes_nothing(ctx, hipmod, S, layout):
     """the 32- and 64-spp size classes run as three kernels (chains; bins + MI; the weights, at two to three times the
@@ -697,12 +720,18 @@ def test_config5_shape_slab_8192x70x64_fp16(ctx, hipmod, oracle):
     assert rel_l2(out[:, r0:r0 + 1, x0:x0 + xw].cpu().numpy(), want) <= REL_L2_BAR
 
 
-@pytest.mark.parametrize("devices,boxes,S", [((0, 0), (7, 5), 8), ((0, 0, 0), (7, 7, 5), 8), ((0, 0), (7,), 16), ((0,), (7, 5), 8)])
+@pytest.mark.parametrize("devices,boxes,S", [((0, 0), (7, 5), 8), ((0, 0, 0), (7, 7, 5), 8), ((0, 0), (7,), 16), ((0,), (7, 5), 8),
+                                             ((0, 1), (7, 5), 8), ((0, 1, 0), (7, 7, 5), 8)])
 def test_multi_context_row_slabs_equal_one_context(ctx, hipmod, oracle, devices, boxes, S):
     """rpf_multi_filter: one caller, one row slab per device entry, colour halo refreshed between passes by device-to-
     device (peer) copies of the neighbours' owned rows.  Rehearsed on the one GPU of this box with several slab contexts
     on device 0: filtered samples, pixel means and merged counters must equal the single-context full-frame call bit for
     bit (the reference filters the whole film every pass, rpf.cpp:732)."""
+    import torch
+    if max(devices) >= torch.cuda.device_count():
+        # the hipMemcpyPeerAsync branch of the halo refresh (two different ordinals) needs a second GPU: unexecuted on the
+        # one-GPU boxes this repository is developed on -- the (0, 0) cases above cover the same offsets with plain copies
+        pytest.skip("needs %d visible GPUs" % (max(devices) + 1))
     W, H = 21, 37
     planes = fb.synth_planes(W, H, S, seed=3, sigma_f=1e-3, sigma_c=0.01, mode="clustered")
     rw = (0.5 + np.random.default_rng(4).random((H, W, S))).astype(np.float32)
