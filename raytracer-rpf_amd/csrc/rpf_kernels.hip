@@ -339,9 +339,9 @@ LdsLayout lds_layout_weights(int S, int nmax, const SampleLayout &lay, int nw) {
     L.nw = (uint32_t)nw;
     L.hist_stride = 1024;
     o += L.hist_stride * L.nw;
-    // the next sample slot's values, staged by global_load_lds: per wave [2 + nF plane values][64 lanes] + 3 fp64 colours as 2 x [64] dwords
+    // the next sample slot's values, staged by global_load_lds: per wave [2 + nF plane values][64 lanes] dwords + 3 fp64 colours as 2 x [64] dwords
     L.off_T = o;
-    o += L.nw * (uint32_t)((2 + lay.nF) * kWave * (int)lay.plane_bytes() + 6 * kWave * 4);
+    o += L.nw * (uint32_t)((2 + lay.nF) * kWave * 4 + 6 * kWave * 4); // (fp16 planes too: the aligned dword around each half)
     L.total = o;
     return L;
 }
