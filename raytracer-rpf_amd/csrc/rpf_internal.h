@@ -90,7 +90,7 @@ struct LdsLayout {
 };
 LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun, const SampleLayout &lay);
 LdsLayout lds_layout_weights(int S, int nmax, const SampleLayout &lay, int nw); // the weight kernel of the split route (32- / 64-spp classes)
-LdsLayout lds_layout_chains(int S, int nmax, const SampleLayout &lay);  // ... and its chain kernel
+LdsLayout lds_layout_chains(int S, int nmax, const SampleLayout &lay, int nw);  // ... and its chain kernel (4 or 8 waves per pixel)
 constexpr int kCarryStride = 136; // doubles per pixel of PassParams::carry (>= kCarry of either layout)
 int samples_per_lane(int nmax); // the K the filter kernel is instantiated with (0 = unsupported)
 bool table_in_lds(int S, int nmax, int bmax, const Tuning &tun, const SampleLayout &lay);

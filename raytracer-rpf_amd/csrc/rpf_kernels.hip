@@ -347,7 +347,7 @@ LdsLayout lds_layout_weights(int S, int nmax, const SampleLayout &lay, int nw) {
 }
 
 // ... and of its chain kernel (PHASE 3): member list, own samples, the producers' staging chunks, 2 KiB of scratch per wave
-LdsLayout lds_layout_chains(int S, int nmax, const SampleLayout &lay) {
+LdsLayout lds_layout_chains(int S, int nmax, const SampleLayout &lay, int nw) {
     LdsLayout L{};
     const uint32_t kNDim = (uint32_t)lay.ndim(), kNPair = (uint32_t)lay.npair();
     uint32_t o = 0;
@@ -359,11 +359,11 @@ LdsLayout lds_layout_chains(int S, int nmax, const SampleLayout &lay) {
     L.off_own = o; o += align_up((uint32_t)S * kNDim * 8u, 16);
     L.off_off = o; o += align_up((uint32_t)nmax * 4u, 16);
     L.off_union = o;
-    L.nw = 4;
+    L.nw = (uint32_t)nw;
     o += align_up((L.nw - 2) * kNDim * (kStageChunk + 1) * 8u, 16); // one staged chunk per producer wave
     L.off_hist = o;
-    L.hist_stride = 2048;
-    o += L.hist_stride * L.nw;
+    L.hist_stride = 0;   // ONE 2-KiB scratch block for the workgroup (block masks of stage 1b, the producers' min / max rows):
+    o += 2048;           // the chain kernel has no per-wave histograms (every wave's sHist aliases wave 0's)
     L.total = o;
     return L;
 }
@@ -398,7 +398,7 @@ hipError_t launch_filter_pass(const PassParams &p, const Tuning &tun, hipStream_
     if (p.carry != nullptr && tun.split_weights != 0 && L.nw == 4 && samples_per_lane(p.nmax) >= 25) {
         const int sweeps = (p.S + (p.lay.is_ref19() ? 15 : 7)) / (p.lay.is_ref19() ? 16 : 8); // own samples per sweep of the weight kernel
         L2 = lds_layout_weights(p.S, p.nmax, p.lay, sweeps <= 2 ? 2 : 4);
-        L3 = lds_layout_chains(p.S, p.nmax, p.lay);
+        L3 = lds_layout_chains(p.S, p.nmax, p.lay, 4);
     }
     const int K = samples_per_lane(p.nmax);
     const bool r19 = p.lay.is_ref19();
