@@ -2,7 +2,9 @@
 """Randomised parity sweep: random frame shapes, sample counts, box sizes, generator modes, policies and beta presets
 through rpf_filter_pass_debug vs the CPU oracle, with the bars of tests/test_gpu_parity.py (bit-exact membership /
 order / bins / statistics, MI 1e-11, alpha/beta/W 1e-9 under both policies, RGB 1e-4 rel-L2).  Round 2: both sample
-layouts (19-dim fp32, 27-dim fp16), boxes up to 21 (neighbourhoods beyond 3136 samples run the streaming kernel).
+layouts (19-dim fp32, 27-dim fp16), boxes up to 21 (neighbourhoods beyond 3136 samples run the streaming kernel).  Round 3:
+flat-quad pixels (zero-variance normals: the stage-1a shortcut, the prelist, the packed kernels at N = S), and every case also
+on the one-wave route (option packed = 0) with bit-identical stage outputs demanded between the two routes.
 usage: fuzz_parity.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,15 +35,21 @@ for i in range(cases):
     policy = int(rng.choice([hip.DEGEN_EPS, hip.DEGEN_EPS, hip.DEGEN_REF_ABORT]))
     beta = int(rng.integers(0, 3))
     seed = int(rng.integers(0, 1 << 30))
+    flat = float(rng.choice([0.0, 0.0, 0.5, 0.94]))
     if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != i:
         continue
-    planes = fb.synth_planes(W, H, S, seed=seed, sigma_f=sf, sigma_c=0.01, mode=mode, dtype="f16" if wide else "f32", **L)
-    got = ctx.filter_pass_debug(planes, hip.make_desc(W, H, S, policy=policy, beta_map=beta,
-                                                      plane_dtype=hip.PLANES_F16 if wide else hip.PLANES_F32, **L),
-                                box=box, allow_nonfinite=True)
+    planes = fb.synth_planes(W, H, S, seed=seed, sigma_f=sf, sigma_c=0.01, mode=mode, dtype="f16" if wide else "f32", flat_frac=flat, **L)
+    desc = hip.make_desc(W, H, S, policy=policy, beta_map=beta, plane_dtype=hip.PLANES_F16 if wide else hip.PLANES_F32, **L)
+    got = ctx.filter_pass_debug(planes, desc, box=box, allow_nonfinite=True)
+    ctx.set_option("packed", 0)
+    old = ctx.filter_pass_debug(planes, desc, box=box, allow_nonfinite=True)
+    ctx.set_option("packed", -1)
     want = O.filter_pass(planes.astype(np.float32), O.make_desc(W, H, S, box=box, policy=policy, beta_map=beta, **L))
     ok, why = True, ""
     try:
+        for k in ("nbhd_size", "member_hash", "bin_hash", "mean", "stddev", "mi", "alpha", "beta", "wrc"):
+            assert np.array_equal(got[k], old[k], equal_nan=True), "packed vs one-wave route: " + k
+        assert np.array_equal(np.isnan(got["colour"]), np.isnan(old["colour"])), "packed vs one-wave route: nan pattern"
         for k in ("nbhd_size", "member_hash", "bin_hash"):
             assert (got[k] == want[k]).all(), k
         assert np.array_equal(got["mean"], want["mean"], equal_nan=True), "mean"
@@ -62,13 +70,18 @@ for i in range(cases):
         ok, why = False, " | ".join(l.strip() for l in str(e).splitlines()[:12] if l.strip()) or "assert"
         fails += 1
         if os.environ.get("FUZZ_ONLY"):
+            print("nonfinite pixels: gpu", got["nonfinite_pixels"], "gpu one-wave route", old["nonfinite_pixels"], "oracle", want["nonfinite_pixels"],
+                  "redo", ctx.counters().redo_pixels, "first bad", got["first_bad_pixel"], want["first_bad_pixel"])
+            gm, wm = ~np.isfinite(got["colour"]).all(axis=(0, 3)), ~np.isfinite(want["colour"]).all(axis=(0, 3))
+            print("pixels NaN on one side only:", np.argwhere(gm != wm).tolist(), "N there:", want["nbhd_size"][gm != wm].tolist())
             bad = np.argwhere(~np.isfinite(want["colour"]).all(axis=(0, 3)))
             print("oracle non-finite pixels (y,x):", bad.tolist(), "gpu:", np.argwhere(~np.isfinite(got["colour"]).all(axis=(0, 3))).tolist())
             for (y, x) in bad.tolist()[:3]:
                 for k in ("nbhd_size", "alpha", "beta", "wrc"):
                     print(k, "gpu", got[k][y, x], "oracle", want[k][y, x])
                 print("mi diff max", np.nanmax(np.abs(got["mi"][y, x] - want["mi"][y, x])))
-    print("%3d %s  %2dx%2dx%2d box %2d %s %-9s sf %-6g policy %d beta %d  maxN %4d bad %d  %s" % (
-        i, "ok  " if ok else "FAIL", W, H, S, box, "d27" if wide else "d19", mode, sf, policy, beta, int(want["nbhd_size"].max()), want["nonfinite_pixels"], why), flush=True)
+    print("%3d %s  %2dx%2dx%2d box %2d %s %-9s sf %-6g flat %-4g policy %d beta %d  maxN %4d small %3d%% bad %d  %s" % (
+        i, "ok  " if ok else "FAIL", W, H, S, box, "d27" if wide else "d19", mode, sf, flat, policy, beta, int(want["nbhd_size"].max()),
+        int(100 * (want["nbhd_size"] <= 64).mean()), want["nonfinite_pixels"], why), flush=True)
 print("fuzz_parity: %d cases, %d failures" % (cases, fails))
 sys.exit(1 if fails else 0)

@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_FLAGS"
+CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-multi-inprocess $BENCH_FLAGS"
 # 1. per-kernel time
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || echo "trace failed"
 # 2. counters, each group in its own pass (no tracing flags alongside --pmc)

@@ -20,15 +20,14 @@ for f, r in rows("trace/**/*kernel_stats.csv"):
     print("%-90s calls %6s total_ns %14s avg_ns %14s pct %6s" % (
         r.get("Name", "")[:90], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
 
-print("== per-dispatch counters, per instantiation of filter_pixel_kernel (mean over its dispatches) ==")
+print("== per-dispatch counters, per kernel of the library (mean over its dispatches) ==")
 acc = defaultdict(lambda: defaultdict(list))
 for f, r in rows("pmc_*/**/*counter_collection.csv"):
     name = r.get("Kernel_Name", "")
-    if "filter_pixel_kernel" not in name:
+    if "rpf::" not in name:
         continue
-    short = name[name.index("filter_pixel_kernel"):].split("(")[0]
-    ns = "d27::" if "d27::" in name else "d19::"
-    acc[ns + short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    short = name.split("(")[0].replace("void ", "").replace("rpf::(anonymous namespace)::", "").replace("rpf::", "")
+    acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 # the instantiation that owns the time first
 order = sorted(acc, key=lambda k: -sum(acc[k].get("GRBM_GUI_ACTIVE", acc[k].get("SQ_WAVE_CYCLES", [0]))))
 for kern in order:

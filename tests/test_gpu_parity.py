@@ -304,6 +304,8 @@ def test_ref_abort_status_on_constant_feature(ctx, hipmod, oracle):
     (21, 13, 1, 7, 0.05, 0.0, 1),    # one sample per pixel: sigma = 0, N = 1, B = 1
     (40, 24, 8, 7, 1e-5, 0.0, 0),    # REF_ABORT on a buffer that completes
     (40, 24, 8, 7, 0.05, 0.94, 0),   # REF_ABORT on the captured-buffer regime: the reference aborts; same NaN pattern
+    (19, 4, 3, 13, 0.02, 0.5, 0),    # box 13 x 3 spp: 507 candidates -> the unbinned route's K = 13 kernel re-routes too (a fuzz find:
+                                     # it did not, and NaN pixels of N = S were counted twice)
 ])
 def test_packed_small_neighbourhood_kernels(ctx, hipmod, oracle, W, H, S, box, sf, flat, policy):
     """N <= 64: the packed kernels (several pixels per wavefront, popcount histograms; rpf_packed_impl.inc) against the

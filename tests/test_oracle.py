@@ -218,3 +218,63 @@ def test_oracle_invariants(oracle):
     cin = planes[2:5].astype(np.float64)
     assert np.array_equal(r["colour"][:, :3], cin[:, :3]) and np.array_equal(r["colour"][:, 6:], cin[:, 6:])
     assert np.array_equal(r["colour"][:, 3:6], r1["colour"][:, 3:6])
+
+
+def test_reflog_matches_libm_next_to_one(tmp_path):
+    """csrc/rpf_reflog.h restates glibc's log() for arguments next to 1 (the REF_ABORT residue path of the streaming kernel
+    evaluates mi.cpp:84 with it on the device).  Compiled for the host, it must equal this machine's libm bit for bit on
+    q = 1 +- k ulp (the only arguments the residue path sees) and on |q - 1| < 2^-10; further out (to 2^-5) libm's own
+    FMA / non-FMA builds differ in the last bit, so only near-total agreement is asked there."""
+    import subprocess
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <cstdint>
+#include <cstdlib>
+#define RPF_HD static inline
+#include "rpf_reflog.h"
+static double fb(uint64_t u){double d; memcpy(&d,&u,8); return d;}
+static uint64_t bits(double d){uint64_t u; memcpy(&u,&d,8); return u;}
+int main(){
+  long bad=0; const uint64_t one = bits(1.0);
+  for (long k=-4096;k<=4096;++k){ double q=fb(one + k); if (bits(rpf::reflog_near_one(q)) != bits(std::log(q))) ++bad; }
+  printf("ulp %ld\n", bad);
+  for (int e=-50;e<=-5;e+=5){ long b2=0,n2=0; srand48(e+100); for(int i=0;i<100000;++i){ double q=1.0+std::ldexp(drand48()*2-1,e);
+      if(!rpf::reflog_in_range(q)) continue; ++n2; if(bits(rpf::reflog_near_one(q))!=bits(std::log(q))) ++b2;} printf("e %d %ld %ld\n", e, b2, n2);}
+}''')
+    exe = tmp_path / "t"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer-rpf_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-I" + inc, "-o", str(exe), str(src)])
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True, check=True).stdout.split("\n")
+    assert out[0] == "ulp 0"
+    for line in out[1:]:
+        if not line:
+            continue
+        _, e, bad, n = line.split()
+        if int(e) <= -10:
+            assert int(bad) == 0, line
+        else:
+            assert int(bad) <= 1e-3 * int(n), line
+
+
+def test_spill_scanner_rules(tmp_path):
+    """scripts/check_spills.py: spill code (scratch stores / reloads, accvgpr copies) between a block label and the first
+    EXEC-enabling instruction is refused -- with waits / scalar moves in between too -- while an `if` body that fetches a
+    parked operand, or the s_mov-and-s_and head of an inner `if`, passes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = {
+        "hazard_plain": ("_Zk:\n.LBB0_1:\n\tscratch_store_dword off, v2, off ; 4-byte Folded Spill\n\ts_or_b64 exec, exec, s[0:1]\n\ts_endpgm\n", 1),
+        "hazard_interleaved": ("_Zk:\n.LBB0_1:\n\ts_waitcnt vmcnt(0)\n\tv_accvgpr_write_b32 a1, v2\n\ts_mov_b32 s5, 0\n\ts_mov_b64 exec, s[0:1]\n\ts_endpgm\n", 1),
+        "hazard_reload": ("_Zk:\n.LBB0_1:\n\tscratch_load_dword v2, off, off ; 4-byte Folded Reload\n\ts_or_b64 exec, exec, s[0:1]\n\ts_endpgm\n", 1),
+        "ok_body": ("_Zk:\n.LBB0_1:\n\tv_accvgpr_read_b32 v4, a1\n\tv_add_f64 v[4:5], v[4:5], v[6:7]\n\ts_or_b64 exec, exec, s[0:1]\n\ts_endpgm\n", 0),
+        "ok_narrow": ("_Zk:\n.LBB0_1:\n\tv_accvgpr_read_b32 v4, a1\n\ts_mov_b64 s[0:1], exec\n\ts_and_b64 s[2:3], s[0:1], vcc\n\ts_mov_b64 exec, s[2:3]\n\ts_endpgm\n", 0),
+    }
+    for name, (txt, want) in cases.items():
+        f = tmp_path / (name + ".s")
+        f.write_text(txt)
+        rc = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_spills.py"), str(f)], stdout=subprocess.PIPE).returncode
+        assert rc == want, name
