@@ -291,6 +291,9 @@ class Job:
 
 def main():
     args = parse()
+    if os.environ.get("RPF_BENCH_WATCHDOG"):   # profiling runs: print every thread's Python stack if the run is still going after N s
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["RPF_BENCH_WATCHDOG"]), exit=False)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))      # before anything touches a GPU
     if args.rendezvous_only:
@@ -332,7 +335,7 @@ def main():
     ctx = hip.Context(local_rank)
     for kv in args.option:
         k, v = kv.split("=")
-        ctx.set_option(k, int(v))
+        ctx.set_option(k, int(v, 0))
 
     job = Job(torch, dist, hip, fb, slabs, args, dev, rank, world, W, rows_per_gpu * world, S, box, layout, ctx,
               gen_kw=wl["gen"], boxes=boxes, policy=policy)
@@ -396,7 +399,7 @@ def main():
             one = job.colour
         out["cpu_baseline"] = cpu_baseline(torch, job.planes, n_own, W, S, box, args.cpu_seconds, one, layout, policy,
                                            full_frame=(args.workload == "cfg1"))
-        if not args.fast_weights and not layout and n_pass == 1:
+        if not args.fast_weights and args.workload == "cfg2":
             # the opt-in fp32 pair-weight mode, measured on the same buffer for information (never `value`)
             ref = job.colour.clone()
             d2 = hip.make_desc(W, job.H_buf, S, boxes=(box,), row_begin=job.desc.row_begin, row_end=job.desc.row_end,

@@ -175,6 +175,9 @@ int32_t rpf_filter_ex(rpf_ctx *ctx, const rpf_desc *desc, const void *planes, co
  *   "packed"           neighbourhoods of N <= 64 samples on the packed kernels (8 / 4 / 2 / 1 pixels per wavefront): -1 auto
  *                      (default: on), 0 off (every pixel gets a whole wavefront), 1 on.  Every stage output up to alpha / beta /
  *                      W_r_c is the same bits either way; colours agree to rounding (~1e-16 relative)
+ *   "count_first"      passes with box*box*S <= 512: stage 1b as its own launch ahead of the filter kernels (the route of
+ *                      small-neighbourhood buffers) or inside filter_pixel_kernel: -1 auto (default: a ~2000-pixel probe
+ *                      decides per pass), 0 fused, 1 count first.  Same results bit for bit; rpf_query_route tells.
  *   "screen"           far-pair screen of the weight stage (four-wave kernels): 1 on (default), 0 off.  Both settings
  *                      give the same filtered colours bit for bit.
  * rpf_counters.options_active tells whether a result was produced under any override. */
@@ -217,6 +220,12 @@ int32_t rpf_query_counters(rpf_ctx *ctx, rpf_counters *out);
  * call left it: nbhd_out host, int32 [H*W] (rows outside the filtered slab: whatever an earlier call left there);
  * count must equal desc W*H of that call.  For workload statistics (mean / percentiles of N). */
 int32_t rpf_query_nbhd(rpf_ctx *ctx, int32_t *nbhd_out, int64_t count);
+
+/* which kernel route the last pass of the most recent call took (a performance decision, the results are the same bits):
+ * 0 = fused (filter_pixel_kernel runs stage 1b itself), 1 = count first (stage 1b as its own launch, then the packed
+ * small-neighbourhood kernels take most pixels: the route of path-traced buffers), 2 = size-binned
+ * (box*box*S > 512), -1 = no pass yet.  Option "count_first" (0 / 1) overrides the probe that chooses between 0 and 1. */
+int32_t rpf_query_route(rpf_ctx *ctx, int32_t *route_out);
 
 /* visualizeSF (rpf.cpp:37-101, visualization/vis.cpp:34-51): the reference's six debug images, without the EXR
  * writer: per-pixel mean over the S samples of n0, n1, p0, p1, (pFilm.x, pFilm.y, 0), (pLens.x, pLens.y, 0), each

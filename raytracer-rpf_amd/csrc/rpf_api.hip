@@ -39,7 +39,8 @@ struct rpf_ctx {
     int32_t *d_status = nullptr;                           // [0] bad count [1] first bad
     unsigned long long *d_nred = nullptr;                  // [0] sum N [1] max N
     uint32_t *d_lists = nullptr; size_t cap_lists = 0;     // size binning: [7][H*W] pixel lists
-    uint32_t *d_class_counts = nullptr;                    // [7]
+    int last_route = -1;                                   // last pass: 1 = count first, 0 = fused, 2 = size-binned (rpf_query_route)
+    uint32_t *d_class_counts = nullptr;                    // [kNumClasses] list sizes + [2] the route probe's counts
     uint64_t *d_masks = nullptr; size_t cap_masks = 0;     // size binning: stage-1b acceptance masks [H*W][stride]
     char *d_big_list = nullptr;  size_t cap_big_list = 0;  // streaming kernel: member lists [slots][nmax] u32
     char *d_big_bins = nullptr;  size_t cap_big_bins = 0;  //                   bin ids [slots][ndim][nmax] u8
@@ -288,19 +289,65 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p_in, hipStream_t s
             HIP_TRY(hipMemsetAsync(ctx->d_class_counts, 0, kNumClasses * sizeof(uint32_t), s));
             q.reroute_masks = ctx->d_masks;
         }
+        // Two routes, same results (tests: option "count_first" 0 / 1).  FUSED: filter_pixel_kernel runs stage 1b itself (its
+        // twelve gathers per candidate hide behind the other stages of the pixels in flight) and re-routes the pixels it finds
+        // small; the route of buffers whose neighbourhoods are large (the headline generator: N = 296 of 392).  COUNT FIRST:
+        // stage 1b for the whole slab as its own launch (nbhd_count_kernel, two phases: a path-traced buffer rejects most
+        // candidates on the first features), then the pixels are dealt by N -- the four packed lists, and the rest (N > 64) into
+        // the list the fused kernel walks, rebuilding its member list from the masks; the route of buffers whose neighbourhoods
+        // are small, where a one-wave workgroup per pixel that only finds out it has nothing to do is the whole cost (6.2 vs
+        // 2.7 ms per 1080p frame).  Which one: a probe -- the test on a lattice of every 32nd pixel of every 32nd row (~2000
+        // pixels of a 1080p frame, ~20 us + a 4-byte read-back): count first when half of them have N <= 64.
+        uint32_t *glist = ctx->d_lists + (size_t)(kNumClasses - 1) * HW, *gcount = ctx->d_class_counts + (kNumClasses - 1);
+        uint32_t *pcount = ctx->d_class_counts + kNumClasses;
+        const uint32_t npix = (uint32_t)((size_t)(p.row_end - p.row_begin) * p.W);
         bool run_main = true;
-        if (packed && ctx->flat_fresh) {
+        int count_first = packed ? ctx->tun.count_first : 0;
+        uint32_t n_general = npix;
+        const bool prelisted = packed && ctx->flat_fresh;
+        if (packed && (count_first < 0 || prelisted)) {
             // pixels that stage 1a proved flat (a zero-variance feature, no NaN mean in the buffer: N = S) never reach the fused
-            // kernel: the others are listed in slab order (the list of the streaming class is free on this route) and the fused
-            // kernel walks that list.  One 4-byte read-back per pass: a one-wave workgroup per flat pixel that only finds out it has
-            // nothing to do cost 5.8 ms per 1080p frame of a captured-like buffer.
-            Range rg("rpf:prelist (flat quads)");
-            uint32_t *glist = ctx->d_lists + (size_t)(kNumClasses - 1) * HW, *gcount = ctx->d_class_counts + (kNumClasses - 1);
-            HIP_TRY(launch_prelist(q, glist, gcount, s));
-            uint32_t n_general = 0;
-            HIP_TRY(hipMemcpyAsync(&n_general, gcount, sizeof(n_general), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            const uint32_t npix = (uint32_t)((size_t)(p.row_end - p.row_begin) * p.W);
+            // kernel or the count pass: the others are listed in slab order (the list of the streaming class is free on this
+            // route): a one-wave workgroup per flat pixel that only finds out it has nothing to do cost 5.8 ms per 1080p frame
+            // of a captured-like buffer.
+            Range rg("rpf:route probe + prelist (flat quads)");
+            uint32_t probe[2] = {0, 0};
+            const int step = 32;
+            if (count_first < 0) {
+                PassParams pr = q;
+                pr.masks = nullptr; pr.reroute_masks = nullptr;
+                if (!ctx->flat_fresh) pr.flat = nullptr;
+                HIP_TRY(hipMemsetAsync(pcount, 0, 2 * sizeof(uint32_t), s));
+                HIP_TRY(launch_nbhd_count(pr, step, pcount, nullptr, nullptr, 0, s));
+                HIP_TRY(hipMemcpyAsync(probe, pcount, sizeof(probe), hipMemcpyDeviceToHost, s));
+            }
+            if (prelisted) {
+                HIP_TRY(launch_prelist(q, glist, gcount, s));
+                HIP_TRY(hipMemcpyAsync(&n_general, gcount, sizeof(n_general), hipMemcpyDeviceToHost, s));
+            }
+            HIP_TRY(hipStreamSynchronize(s)); // one read-back for both
+            if (count_first < 0) {
+                const uint32_t n_probe = (uint32_t)((p.W + step - 1) / step) * (uint32_t)((p.row_end - p.row_begin + step - 1) / step);
+                const uint32_t n_probe_general = n_probe - std::min(n_probe, probe[1]);
+                count_first = (n_probe_general != 0 && 2u * probe[0] >= n_probe_general) ? 1 : 0; // (only flat pixels: nothing to count)
+            }
+        }
+        ctx->last_route = count_first;
+        if (count_first == 1 && n_general != 0) {
+            Range rg("rpf:stage 1b + classify");
+            uint32_t *rlist = ctx->d_lists + (size_t)(kNumClasses - 2) * HW, *rcount = ctx->d_class_counts + (kNumClasses - 2);
+            uint32_t n_rest = 0;
+            q.reroute_masks = nullptr;
+            q.masks = ctx->d_masks;
+            if (!ctx->flat_fresh) q.flat = nullptr;
+            if (prelisted && n_general < npix) { HIP_TRY(launch_nbhd_count(q, 1, nullptr, glist, gcount, n_general, s)); }
+            else { HIP_TRY(launch_nbhd_count(q, 1, nullptr, nullptr, nullptr, 0, s)); }
+            HIP_TRY(launch_classify(q, ctx->d_lists, ctx->d_class_counts, kNumPacked, kNumClasses - 2, s));
+            HIP_TRY(hipMemcpyAsync(&n_rest, rcount, sizeof(n_rest), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s)); // the fused kernel's grid
+            if (n_rest != 0) { q.pix_list = rlist; q.list_count = n_rest; }
+            else run_main = false;
+        } else if (prelisted) {
             if (n_general == 0) run_main = false;
             else if (n_general < npix) { q.pix_list = glist; q.list_count = n_general; }
         }
@@ -312,7 +359,7 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p_in, hipStream_t s
         q.pix_list = nullptr; q.list_count = 0;
         if (packed) {
             Range rg("rpf:packed kernels (N <= 8, 16, 32, 64)");
-            HIP_TRY(launch_classify(q, ctx->d_lists, ctx->d_class_counts, kNumPacked, s));
+            if (!(count_first == 1 && n_general != 0)) { HIP_TRY(launch_classify(q, ctx->d_lists, ctx->d_class_counts, kNumPacked, -1, s)); }
             for (int c = 0; c < kNumPacked; ++c) {
                 if (p.S > class_capacity(c)) continue; // N >= S: the list is empty by construction
                 PassParams r = q;
@@ -328,6 +375,7 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p_in, hipStream_t s
         }
         return launch_redo(ctx, p, s, launches);
     }
+    ctx->last_route = 2;
     if ((st = ensure(ctx, ctx->d_lists, ctx->cap_lists, (size_t)kNumClasses * HW * sizeof(uint32_t)))) return st;
     // the count pass keeps its acceptance masks (one u64 per 64 candidates) so the filter kernels only rebuild the list
     PassParams pc = p;
@@ -348,8 +396,8 @@ int32_t launch_filter_binned(rpf_ctx *ctx, const PassParams &p_in, hipStream_t s
         Range rg("rpf:count + classify (stage 1b test, size classes)");
         ctx->bin_valid = false;
         HIP_TRY(hipMemsetAsync(ctx->d_class_counts, 0, kNumClasses * sizeof(uint32_t), s));
-        HIP_TRY(launch_nbhd_count(pc, s));
-        HIP_TRY(launch_classify(pc, ctx->d_lists, ctx->d_class_counts, kNumClasses, s));
+        HIP_TRY(launch_nbhd_count(pc, 1, nullptr, nullptr, nullptr, 0, s));
+        HIP_TRY(launch_classify(pc, ctx->d_lists, ctx->d_class_counts, kNumClasses, -1, s));
         HIP_TRY(hipMemcpyAsync(counts, ctx->d_class_counts, sizeof(counts), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         std::memcpy(ctx->bin_counts, counts, sizeof(counts));
@@ -645,7 +693,7 @@ int32_t rpf_create(rpf_ctx **out, int32_t device) {
     HIP_TRY(hipStreamCreateWithFlags(&ctx->s_down, hipStreamNonBlocking));
     HIP_TRY(hipMalloc((void **)&ctx->d_status, 2 * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->d_nred, 2 * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc((void **)&ctx->d_class_counts, kNumClasses * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->d_class_counts, (kNumClasses + 2) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->d_nan_flag, sizeof(int32_t)));
     HIP_TRY(hipMemset(ctx->d_nan_flag, 0, sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->d_redo_count, sizeof(uint32_t)));
@@ -751,6 +799,7 @@ int32_t rpf_set_option(rpf_ctx *ctx, const char *name, int64_t value) {
     else if (n == "split_weights" && value >= -1 && value <= 1) t.split_weights = (int32_t)value;
     else if (n == "strip_w" && value >= 0 && value <= 4096 && value % 8 == 0) t.strip_w = (int32_t)value;
     else if (n == "packed" && value >= -1 && value <= 1) t.packed = (int32_t)value;
+    else if (n == "count_first" && value >= -1 && value <= 1) t.count_first = (int32_t)value;
     else if (n == "lds_pad" && value >= 0 && value <= 160 * 1024) t.lds_pad = (int32_t)value;
     else return fail(ctx, RPF_E_BADARG, "unknown option or value out of range: " + n);
     ctx->bin_valid = false;
@@ -981,6 +1030,13 @@ int32_t rpf_query_nbhd(rpf_ctx *ctx, int32_t *nbhd_out, int64_t count) {
         return fail(ctx, RPF_E_BADARG, "no neighbourhood plane of that size: run a filter call first (count = W*H)");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpy(nbhd_out, ctx->d_nbhd, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return RPF_OK;
+}
+
+int32_t rpf_query_route(rpf_ctx *ctx, int32_t *route_out) {
+    if (!ctx) return RPF_E_BADARG;
+    if (!route_out) return fail(ctx, RPF_E_BADARG, "route_out is NULL");
+    *route_out = ctx->last_route;
     return RPF_OK;
 }
 

@@ -79,8 +79,9 @@ struct Tuning {
     int32_t screen = 1;          // far-pair screen (stage 4, four-wave kernels): 0 off, 1 on; same results
     int32_t split_weights = -1;  // 32- / 64-spp classes as three kernels (chains; bins + MI; weights): -1 auto (on), 0 off, 1 on; same results
     int32_t strip_w = 0;         // pixels per XCD strip of the pixel walk: 0 auto (by box and spp), else a multiple of 8; same results
+    int32_t count_first = -1;    // box*box*S <= 512: stage 1b as its own launch ahead of the filter kernels (the small-N route): -1 auto (probe), 0 off, 1 on; same results
     int32_t packed = -1;         // small neighbourhoods (N <= 64) on the packed kernels, several pixels per wave: -1 auto (on), 0 off, 1 on
-    bool is_default() const { return waves_per_pixel == 0 && table_in_lds == -1 && lds_pad == 0 && binning == -1 && stage_mask == -1 && screen == 1 && strip_w == 0 && split_weights == -1 && packed == -1; }
+    bool is_default() const { return waves_per_pixel == 0 && table_in_lds == -1 && lds_pad == 0 && binning == -1 && stage_mask == -1 && screen == 1 && strip_w == 0 && count_first == -1 && split_weights == -1 && packed == -1; }
 };
 
 struct LdsLayout {
@@ -109,14 +110,18 @@ int class_capacity(int c);          // 8, 16, 32, 64, 128, 256, 448, 832, 1600, 
 // the packed kernels (rpf_packed_impl.inc): pixels of p.pix_list with N <= lanes_per_pixel; count_dev != null: the list size
 // is read on the device and p.list_count is only its upper bound
 hipError_t launch_filter_packed(const PassParams &p, int lanes_per_pixel, const uint32_t *count_dev, hipStream_t s);
-hipError_t launch_nbhd_count(const PassParams &p, hipStream_t s);
+// stage 1b's test (N and the acceptance masks): for every pixel of the slab (step 1, list null); for the entries of `list`
+// (size on the device in *list_count, at most list_max: sizes the grid); or for the points of a lattice of pitch `step`, with
+// probe[0] += how many of them have N <= 64 without being proven flat and probe[1] += how many are proven flat
+hipError_t launch_nbhd_count(const PassParams &p, int step, uint32_t *probe, const uint32_t *list, const uint32_t *list_count,
+                             uint32_t list_max, hipStream_t s);
 // the streaming kernel (neighbourhoods of the last size class): global scratch of `slots` workgroups,
 // list [slots][nmax] u32 and bins [slots][ndim][nmax] u8
 // count_dev != null: the size of p.pix_list is read from device memory (redo mode: no host read-back), grid = slots
 hipError_t launch_filter_big(const PassParams &p, void *list, void *bins, uint32_t slots, const uint32_t *count_dev, hipStream_t s);
-// max_class < kNumClasses: pixels of that class and above are left out (the unbinned route lists the packed classes only)
+// max_class < kNumClasses: pixels of that class and above join the list of rest_class (-1: they are left out)
 hipError_t launch_classify(const PassParams &p, uint32_t *lists /*[kNumClasses][H*W]*/, uint32_t *counts /*[kNumClasses], zeroed*/,
-                           int max_class, hipStream_t s);
+                           int max_class, int rest_class, hipStream_t s);
 hipError_t launch_colour_from_planes(const void *planes, bool f16, double *colour, uint64_t plane_stride, hipStream_t s);
 hipError_t launch_colour_from_planes_span(const void *planes, bool f16, double *colour, uint64_t plane_stride, uint64_t e0,
                                           uint64_t cnt, hipStream_t s);

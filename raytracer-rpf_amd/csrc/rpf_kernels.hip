@@ -38,7 +38,7 @@ struct ClassCaps { int cap[kNumClasses]; };
 
 // pixels in slab_pixel order -> one list per class (class = first capacity >= N); lists[c][*], counts[c]
 __global__ __launch_bounds__(256) void classify_kernel(PassParams p, ClassCaps caps, uint32_t *lists, uint32_t *counts,
-                                                       uint64_t list_stride, int max_class) {
+                                                       uint64_t list_stride, int max_class, int rest_class) {
     const int lane = threadIdx.x & (kWave - 1);
     const int rows_band = (p.row_end - p.row_begin + 7) / 8;
     const int64_t per_band = (int64_t)rows_band * p.W;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void classify_kernel(PassParams p, ClassCaps c
 #pragma unroll
         for (int c = kNumClasses - 2; c >= 0; --c)
             if (n <= caps.cap[c]) cls = c;
-        if (cls >= max_class) cls = -1;
+        if (cls >= max_class) cls = rest_class; // (-1: not listed)
     }
     // one atomic per class and WORKGROUP (a per-wave append serialises on the class counter: 1.1 ms per 1080p frame when two
     // classes share the frame); positions inside the workgroup keep the slab order
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void nbhd_reduce_kernel(const int32_t *nbhd, u
     hipError_t impl_filter_mid(const PassParams &p, const LdsLayout &L, const LdsLayout &L2, const LdsLayout &L3, bool t_in_lds, unsigned grid, hipStream_t s); \
     hipError_t impl_filter_large(const PassParams &p, const LdsLayout &L, const LdsLayout &L2, const LdsLayout &L3, bool t_in_lds, unsigned grid, hipStream_t s); \
     hipError_t impl_pixel_stats(const PassParams &p, uint64_t pix0, uint64_t pix1, hipStream_t s);                        \
-    hipError_t impl_nbhd_count(const PassParams &p, unsigned grid, hipStream_t s);                                        \
+    hipError_t impl_nbhd_count(const PassParams &p, int step, uint32_t *probe, const uint32_t *list, const uint32_t *list_count, uint32_t list_max, hipStream_t s); \
     hipError_t impl_filter_big(const PassParams &p, void *list, void *bins, uint32_t slots, const uint32_t *count_dev, hipStream_t s); \
     hipError_t impl_filter_packed(const PassParams &p, int lanes_per_pixel, const uint32_t *count_dev, hipStream_t s);    \
     }
@@ -413,11 +413,10 @@ int class_capacity(int c) {
     return caps[c];
 }
 
-hipError_t launch_nbhd_count(const PassParams &p, hipStream_t s) {
-    const int64_t npix = (int64_t)(p.row_end - p.row_begin) * p.W;
-    if (npix <= 0) return hipSuccess;
-    const unsigned grid = (unsigned)((npix + 3) / 4);
-    return p.lay.is_ref19() ? d19::impl_nbhd_count(p, grid, s) : d27::impl_nbhd_count(p, grid, s);
+hipError_t launch_nbhd_count(const PassParams &p, int step, uint32_t *probe, const uint32_t *list, const uint32_t *list_count, uint32_t list_max, hipStream_t s) {
+    if (!p.lay.supported() || step < 1) return hipErrorInvalidValue;
+    return p.lay.is_ref19() ? d19::impl_nbhd_count(p, step, probe, list, list_count, list_max, s)
+                            : d27::impl_nbhd_count(p, step, probe, list, list_count, list_max, s);
 }
 
 hipError_t launch_filter_packed(const PassParams &p, int lanes_per_pixel, const uint32_t *count_dev, hipStream_t s) {
@@ -430,13 +429,13 @@ hipError_t launch_filter_big(const PassParams &p, void *list, void *bins, uint32
     return p.lay.is_ref19() ? d19::impl_filter_big(p, list, bins, slots, count_dev, s) : d27::impl_filter_big(p, list, bins, slots, count_dev, s);
 }
 
-hipError_t launch_classify(const PassParams &p, uint32_t *lists, uint32_t *counts, int max_class, hipStream_t s) {
+hipError_t launch_classify(const PassParams &p, uint32_t *lists, uint32_t *counts, int max_class, int rest_class, hipStream_t s) {
     const int64_t total = (int64_t)((p.row_end - p.row_begin + 7) / 8) * p.W * 8;
     if (total <= 0) return hipSuccess;
     ClassCaps caps;
     for (int c = 0; c < kNumClasses; ++c) caps.cap[c] = class_capacity(c);
     hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, caps, lists, counts,
-                       (uint64_t)p.H * p.W, max_class);
+                       (uint64_t)p.H * p.W, max_class, rest_class);
     return hipGetLastError();
 }
 

@@ -29,7 +29,7 @@ EXPORTS = ["rpf_version", "rpf_status_string", "rpf_create", "rpf_destroy", "rpf
            "rpf_filter_pass_debug", "rpf_query_counters", "rpf_lds_bytes_required", "rpf_selftest_udiv", "rpf_feature_images",
            "rpf_host_alloc", "rpf_host_free", "rpf_filter_ex", "rpf_set_option", "rpf_multi_create", "rpf_multi_destroy",
            "rpf_multi_last_error", "rpf_multi_device_count", "rpf_multi_set_option", "rpf_multi_filter",
-           "rpf_multi_query_counters", "rpf_query_nbhd"]
+           "rpf_multi_query_counters", "rpf_query_nbhd", "rpf_query_route"]
 
 
 class Desc(C.Structure):
@@ -103,6 +103,7 @@ def load():
                                             C.c_void_p, C.POINTER(Debug)]
         L.rpf_query_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
         L.rpf_query_nbhd.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.rpf_query_route.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.rpf_selftest_udiv.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_uint64)]
         L.rpf_feature_images.argtypes = [C.c_void_p, C.POINTER(Desc), C.c_void_p, C.c_void_p]
         L.rpf_lds_bytes_required.restype = C.c_int64
@@ -191,6 +192,12 @@ class Context:
         out = np.empty((H, W), np.int32)
         self._check(self._L.rpf_query_nbhd(self._h, _p(out), W * H))
         return out
+
+    def route(self):
+        """kernel route of the last pass: 0 fused, 1 count first, 2 size-binned (rpf_query_route)"""
+        r = C.c_int32(-1)
+        self._check(self._L.rpf_query_route(self._h, C.byref(r)))
+        return r.value
 
     # ---- host-buffer entry points ------------------------------------------------------------------
     def host_empty(self, shape, dtype=np.float32):

@@ -6,14 +6,24 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+export RPF_BENCH_WATCHDOG=150
 CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-multi-inprocess $BENCH_FLAGS"
+# every pass runs under its own limit; a pass that is killed at the limit ends the script (no further GPU step after a hang)
+LIM=${PASS_LIMIT:-240}
+pass() {  # pass <name> <rocprofv3 args...>
+    local name=$1; shift
+    timeout -k 10 $LIM rocprofv3 "$@" --output-format csv -d $OUT/$name -- $CMD > $OUT/$name.log 2>&1
+    local rc=$?
+    echo "pass $name rc=$rc"
+    if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pass $name hit its limit: stopping"; python3 scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1; exit 3; fi
+}
 # 1. per-kernel time
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || echo "trace failed"
+pass trace --kernel-trace --stats
 # 2. counters, each group in its own pass (no tracing flags alongside --pmc)
-rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc_lds -- $CMD > $OUT/pmc_lds.log 2>&1 || echo "pmc_lds failed"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1 || echo "pmc_fetch failed"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1 || echo "pmc_write failed"
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/pmc_sq.log 2>&1 || echo "pmc_sq failed"
+pass pmc_lds --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS
+pass pmc_fetch --pmc FETCH_SIZE
+pass pmc_sq --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES GRBM_GUI_ACTIVE
+pass pmc_write --pmc WRITE_SIZE
 find $OUT -name "*.csv" | head -40
 python3 scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

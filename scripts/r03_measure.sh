@@ -15,13 +15,13 @@ bash scripts/sweep.sh > $O/spp_sweep.txt 2>&1; cat $O/spp_sweep.txt
 (SPP=8 python scripts/smalln.py; SPP=16 python scripts/smalln.py; SPP=32 ROWS=540 python scripts/smalln.py; SPP=64 ROWS=270 python scripts/smalln.py) 2>&1 | grep -v amdgpu > $O/smalln.txt; grep -c kernel_ms $O/smalln.txt
 fi
 if part prof; then
-bash scripts/profile.sh r03_1080p8 > $O/prof_1080p8.log 2>&1; tail -3 $O/prof_1080p8.log
-BENCH_FLAGS="--no-scaling-4k32 --width 3840 --rows-per-gpu 270 --spp 32" bash scripts/profile.sh r03_4k32slab > $O/prof_4k32slab.log 2>&1; tail -3 $O/prof_4k32slab.log
-BENCH_FLAGS="--no-scaling-4k32 --spp 16" bash scripts/profile.sh r03_16spp > $O/prof_16spp.log 2>&1; tail -3 $O/prof_16spp.log
-BENCH_FLAGS="--workload cfg3" bash scripts/profile.sh r03_cfg3 > $O/prof_cfg3.log 2>&1; tail -3 $O/prof_cfg3.log
+bash scripts/profile.sh r03_1080p8 > $O/prof_1080p8.log 2>&1 || { cat $O/prof_1080p8.log; exit 3; }; tail -3 $O/prof_1080p8.log
+BENCH_FLAGS="--no-scaling-4k32 --width 3840 --rows-per-gpu 270 --spp 32" bash scripts/profile.sh r03_4k32slab > $O/prof_4k32slab.log 2>&1 || { cat $O/prof_4k32slab.log; exit 3; }; tail -3 $O/prof_4k32slab.log
+BENCH_FLAGS="--no-scaling-4k32 --spp 16" bash scripts/profile.sh r03_16spp > $O/prof_16spp.log 2>&1 || { cat $O/prof_16spp.log; exit 3; }; tail -3 $O/prof_16spp.log
+BENCH_FLAGS="--workload cfg3" bash scripts/profile.sh r03_cfg3 > $O/prof_cfg3.log 2>&1 || { cat $O/prof_cfg3.log; exit 3; }; tail -3 $O/prof_cfg3.log
 fi
 if part prof5; then
-BENCH_FLAGS="--workload cfg5 --steps 1" bash scripts/profile.sh r03_cfg5 > $O/prof_cfg5.log 2>&1; tail -3 $O/prof_cfg5.log
+BENCH_FLAGS="--workload cfg5 --steps 1" bash scripts/profile.sh r03_cfg5 > $O/prof_cfg5.log 2>&1 || { cat $O/prof_cfg5.log; exit 3; }; tail -3 $O/prof_cfg5.log
 fi
 if part marker; then
 rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d $O/marker -- python3 bench.py --workload cfg3 --steps 1 --warmup 1 --no-cpu-baseline > $O/marker.log 2>&1

@@ -3,8 +3,8 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r03d
 CASE=${CASE:-2}
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/r03d/pmc_a -- python3 scripts/smalln.py > gpurun_out/r03d/pmc_a.log 2>&1
-rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d gpurun_out/r03d/pmc_b -- python3 scripts/smalln.py > gpurun_out/r03d/pmc_b.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/r03d/pmc_a -- python3 scripts/smalln.py > gpurun_out/r03d/pmc_a.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d gpurun_out/r03d/pmc_b -- python3 scripts/smalln.py > gpurun_out/r03d/pmc_b.log 2>&1
 python3 - <<'PY'
 import csv, glob
 from collections import defaultdict

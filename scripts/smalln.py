@@ -29,6 +29,8 @@ for sf, flat in cases:
     for packed in PACKED:
         ctx = hip.Context(0)
         ctx.set_option("packed", packed)
+        if os.environ.get("COUNT_FIRST"):
+            ctx.set_option("count_first", int(os.environ["COUNT_FIRST"]))
         desc = hip.make_desc(W, H, S, boxes=(7,), policy=hip.DEGEN_EPS, flags=hip.FLAG_TIMING)
         ms = []
         for _ in range(4):

@@ -333,6 +333,51 @@ def test_packed_small_neighbourhood_kernels(ctx, hipmod, oracle, W, H, S, box, s
     np.testing.assert_allclose(got["colour"][m], old["colour"][m], rtol=1e-12, atol=1e-300)
 
 
+@pytest.mark.parametrize("W,H,S,box,sf,flat,ndim,auto", [
+    (45, 27, 8, 7, 3e-3, 0.3, 19, None),  # 1080p shape in small: every pixel class of the unbinned route
+    (64, 40, 8, 7, 1e-5, 0.0, 19, 1),     # small neighbourhoods everywhere: the probe picks the count-first route
+    (64, 40, 8, 7, 0.05, 0.0, 19, 0),     # large ones: the probe keeps stage 1b inside the fused kernel
+    (29, 19, 3, 5, 0.02, 0.0, 19, None),  # S not a power of two, box 5, a NaN sample
+    (9, 5, 8, 7, 0.05, 0.0, 19, None),    # windows clipped on every side
+    (21, 12, 8, 5, 1e-2, 0.3, 27, None),  # 27-dim layout, fp16 planes
+])
+def test_count_first_route_equals_fused_route(hipmod, oracle, W, H, S, box, sf, flat, ndim, auto):
+    """box*box*S <= 512 has two kernel routes: stage 1b inside filter_pixel_kernel (option "count_first" = 0) or as its own
+    two-phase launch ahead of the filter kernels (1; nbhd_count_kernel: candidates that fail the first features never have the
+    others gathered).  N, member order and everything downstream must be the same bits, whichever the probe picks."""
+    kw = dict(n_random=4, n_feat=18, dtype="f16") if ndim == 27 else {}
+    lay = dict(n_random=4, n_feat=18, plane_dtype=hipmod.PLANES_F16) if ndim == 27 else {}
+    planes = fb.synth_planes(W, H, S, seed=33, sigma_f=sf, sigma_c=0.01, mode="smooth", flat_frac=flat, **kw)
+    if flat == 0.0 and auto is None:  # (a NaN mean anywhere switches the stage-1a flat proof off for the frame)
+        planes[10, 3, 5, 1 % S] = np.nan  # a NaN feature sample: passes the feature it is NaN in (ops.h:101-104), rejects nobody else
+    desc = hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS, **lay)
+    res = {}
+    for cf in (0, 1, -1):
+        with hipmod.Context(0) as c:
+            c.set_option("count_first", cf)
+            res[cf] = c.filter_pass_debug(planes, desc, box=box, allow_nonfinite=True)
+            route = c.route()
+        assert route == cf if cf >= 0 else route in (0, 1)
+        if cf < 0 and auto is not None:
+            assert route == auto
+    if ndim == 19:
+        want = oracle.filter_pass(planes, oracle.make_desc(W, H, S, box=box, policy=oracle.DEGEN_EPS))
+        assert np.array_equal(res[0]["nbhd_size"], want["nbhd_size"]) and np.array_equal(res[0]["member_hash"], want["member_hash"])
+    for cf in (1, -1):
+        for k in ("nbhd_size", "member_hash", "bin_hash", "mean", "stddev", "mi", "alpha", "beta", "wrc", "colour"):
+            assert np.array_equal(res[cf][k], res[0][k], equal_nan=True), (cf, k)
+        assert res[cf]["status"] == res[0]["status"] and res[cf]["nonfinite_pixels"] == res[0]["nonfinite_pixels"]
+    # a row slab: the probe lattice and the count pass start at row_begin, windows reach into the halo rows
+    r0, r1 = 2, H - 1
+    dslab = hipmod.make_desc(W, H, S, policy=hipmod.DEGEN_EPS, row_begin=r0, row_end=r1, **lay)
+    with hipmod.Context(0) as c2:
+        c2.set_option("count_first", 1)
+        a = c2.filter_pass_debug(planes, dslab, box=box, allow_nonfinite=True)
+    for k in ("nbhd_size", "member_hash"):
+        assert np.array_equal(a[k][r0:r1], res[0][k][r0:r1]), k
+    assert np.array_equal(a["colour"][:, r0:r1], res[0]["colour"][:, r0:r1], equal_nan=True)
+
+
 @pytest.mark.parametrize("S", [8, 16])
 def test_flat_quad_shortcut_and_nan_candidates(ctx, hipmod, oracle, S):
     """Stage 1b's flat-quad shortcut: a pixel with a zero-variance feature rejects every finite candidate (3 sigma = 0, strict
