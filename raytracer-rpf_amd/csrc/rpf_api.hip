@@ -799,6 +799,7 @@ int32_t rpf_set_option(rpf_ctx *ctx, const char *name, int64_t value) {
     else if (n == "split_weights" && value >= -1 && value <= 1) t.split_weights = (int32_t)value;
     else if (n == "strip_w" && value >= 0 && value <= 4096 && value % 8 == 0) t.strip_w = (int32_t)value;
     else if (n == "packed" && value >= -1 && value <= 1) t.packed = (int32_t)value;
+    else if (n == "split_chunk" && value >= 0 && value <= (1 << 30)) t.split_chunk = (int32_t)value;
     else if (n == "count_first" && value >= -1 && value <= 1) t.count_first = (int32_t)value;
     else if (n == "lds_pad" && value >= 0 && value <= 160 * 1024) t.lds_pad = (int32_t)value;
     else return fail(ctx, RPF_E_BADARG, "unknown option or value out of range: " + n);

@@ -78,10 +78,11 @@ struct Tuning {
     int32_t stage_mask = -1;     // bit0 stats chain, bit1 bins, bit2 MI, bit3 weights; -1 = all
     int32_t screen = 1;          // far-pair screen (stage 4, four-wave kernels): 0 off, 1 on; same results
     int32_t split_weights = -1;  // 32- / 64-spp classes as three kernels (chains; bins + MI; weights): -1 auto (on), 0 off, 1 on; same results
+    int32_t split_chunk = 0;     // split route: run its three launches chunk by chunk over this many list entries (0 = the whole list at once); same results
     int32_t strip_w = 0;         // pixels per XCD strip of the pixel walk: 0 auto (by box and spp), else a multiple of 8; same results
     int32_t count_first = -1;    // box*box*S <= 512: stage 1b as its own launch ahead of the filter kernels (the small-N route): -1 auto (probe), 0 off, 1 on; same results
     int32_t packed = -1;         // small neighbourhoods (N <= 64) on the packed kernels, several pixels per wave: -1 auto (on), 0 off, 1 on
-    bool is_default() const { return waves_per_pixel == 0 && table_in_lds == -1 && lds_pad == 0 && binning == -1 && stage_mask == -1 && screen == 1 && strip_w == 0 && count_first == -1 && split_weights == -1 && packed == -1; }
+    bool is_default() const { return waves_per_pixel == 0 && table_in_lds == -1 && lds_pad == 0 && binning == -1 && stage_mask == -1 && screen == 1 && strip_w == 0 && split_chunk == 0 && count_first == -1 && split_weights == -1 && packed == -1; }
 };
 
 struct LdsLayout {

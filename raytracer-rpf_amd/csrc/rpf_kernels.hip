@@ -403,6 +403,21 @@ hipError_t launch_filter_pass(const PassParams &p, const Tuning &tun, hipStream_
     const int K = samples_per_lane(p.nmax);
     const bool r19 = p.lay.is_ref19();
     if (K == 0) return hipErrorInvalidValue;
+    if (L2.total != 0 && tun.split_chunk > 0 && p.pix_list != nullptr && p.list_count > (uint32_t)tun.split_chunk) {
+        // experiment (option "split_chunk"): the three launches of the split route over one chunk of the pixel list after the
+        // other, so that a chunk's samples, masks and hand-over records are still in the 256 MiB Infinity Cache when the next
+        // phase gathers them again (the list is in slab order: a chunk is a band of strips)
+        for (uint32_t off = 0; off < p.list_count; off += (uint32_t)tun.split_chunk) {
+            PassParams q = p;
+            q.pix_list = p.pix_list + off;
+            q.list_count = (p.list_count - off < (uint32_t)tun.split_chunk) ? p.list_count - off : (uint32_t)tun.split_chunk;
+            const unsigned g = (unsigned)(((q.list_count + 7u) / 8u) * 8u);
+            const hipError_t e = K <= 25 ? (r19 ? d19::impl_filter_mid(q, L, L2, L3, t_in_lds, g, s) : d27::impl_filter_mid(q, L, L2, L3, t_in_lds, g, s))
+                                         : (r19 ? d19::impl_filter_large(q, L, L2, L3, t_in_lds, g, s) : d27::impl_filter_large(q, L, L2, L3, t_in_lds, g, s));
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
     if (K <= 8) return r19 ? d19::impl_filter_small(p, L, t_in_lds, grid, s) : d27::impl_filter_small(p, L, t_in_lds, grid, s);
     if (K <= 25) return r19 ? d19::impl_filter_mid(p, L, L2, L3, t_in_lds, grid, s) : d27::impl_filter_mid(p, L, L2, L3, t_in_lds, grid, s);
     return r19 ? d19::impl_filter_large(p, L, L2, L3, t_in_lds, grid, s) : d27::impl_filter_large(p, L, L2, L3, t_in_lds, grid, s);

@@ -4,7 +4,8 @@ through rpf_filter_pass_debug vs the CPU oracle, with the bars of tests/test_gpu
 order / bins / statistics, MI 1e-11, alpha/beta/W 1e-9 under both policies, RGB 1e-4 rel-L2).  Round 2: both sample
 layouts (19-dim fp32, 27-dim fp16), boxes up to 21 (neighbourhoods beyond 3136 samples run the streaming kernel).  Round 3:
 flat-quad pixels (zero-variance normals: the stage-1a shortcut, the prelist, the packed kernels at N = S), and every case also
-on the one-wave route (option packed = 0) with bit-identical stage outputs demanded between the two routes.
+on the one-wave route (option packed = 0) with bit-identical stage outputs demanded between the two routes; the packed run
+takes the probe's route, the fused route and the count-first route in turn (option count_first).
 usage: fuzz_parity.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,7 +41,9 @@ for i in range(cases):
         continue
     planes = fb.synth_planes(W, H, S, seed=seed, sigma_f=sf, sigma_c=0.01, mode=mode, dtype="f16" if wide else "f32", flat_frac=flat, **L)
     desc = hip.make_desc(W, H, S, policy=policy, beta_map=beta, plane_dtype=hip.PLANES_F16 if wide else hip.PLANES_F32, **L)
+    ctx.set_option("count_first", (-1, 0, 1)[i % 3])   # the probe's choice, the fused route, the count-first route (box*box*S <= 512)
     got = ctx.filter_pass_debug(planes, desc, box=box, allow_nonfinite=True)
+    ctx.set_option("count_first", -1)
     ctx.set_option("packed", 0)
     old = ctx.filter_pass_debug(planes, desc, box=box, allow_nonfinite=True)
     ctx.set_option("packed", -1)

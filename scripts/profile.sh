@@ -6,13 +6,17 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-export RPF_BENCH_WATCHDOG=150
+export RPF_BENCH_WATCHDOG=100
 CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-multi-inprocess $BENCH_FLAGS"
 # every pass runs under its own limit; a pass that is killed at the limit ends the script (no further GPU step after a hang)
-LIM=${PASS_LIMIT:-240}
+LIM=${PASS_LIMIT:-160}
 pass() {  # pass <name> <rocprofv3 args...>
     local name=$1; shift
-    timeout -k 10 $LIM rocprofv3 "$@" --output-format csv -d $OUT/$name -- $CMD > $OUT/$name.log 2>&1
+    local cmd="$CMD"
+    # counter passes skip the 3840x2160x32 strong-scaling leg of the default workload: it has its own profile (r03_4k32slab), and
+    # a counter-collection run of it hung inside the profiler twice this round (bench.py's watchdog: stuck in the filter call)
+    if [ "$name" != trace ] && [[ "$cmd" != *--no-scaling-4k32* ]]; then cmd="$cmd --no-scaling-4k32"; fi
+    timeout -k 10 $LIM rocprofv3 "$@" --output-format csv -d $OUT/$name -- $cmd > $OUT/$name.log 2>&1
     local rc=$?
     echo "pass $name rc=$rc"
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pass $name hit its limit: stopping"; python3 scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1; exit 3; fi

@@ -611,6 +611,12 @@ def test_split_weight_kernel_changes_nothing(ctx, hipmod, S, layout):
     finally:
         ctx.set_option("split_weights", -1)
     assert on["max_nbhd"] > (1600 if S == 64 else 832)  # the K = 49 / K = 25 class ran
+    ctx.set_option("split_chunk", 17)                    # the three launches over 17 list entries at a time (ragged last chunk)
+    try:
+        chunked = ctx.filter_pass_debug(planes, desc, box=7)
+    finally:
+        ctx.set_option("split_chunk", 0)
+    assert np.array_equal(on["colour"], chunked["colour"], equal_nan=True) and np.array_equal(on["mi"], chunked["mi"], equal_nan=True)
     assert np.array_equal(on["colour"], off["colour"], equal_nan=True)
     for k in ("alpha", "beta", "wrc", "mi", "mean", "stddev"):
         assert np.array_equal(on[k], off[k], equal_nan=True), k
