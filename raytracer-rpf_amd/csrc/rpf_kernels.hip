@@ -289,7 +289,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun
     uint32_t o = 0;
     L.off_T = o;
     if (t_in_lds) o += align_up((uint32_t)nmax * 8u, 16);
-    else if (K <= 8) o += (uint32_t)kDHead * 8u; // the one-wave kernels keep the head of the D table in LDS
+    else if (K <= 13) o += (uint32_t)kDHead * 8u; // the one-wave kernels keep the head of the D table in LDS
     L.off_stat = o; o += align_up(4 * kNDim * 8, 16);
     L.off_hx = o; o += align_up(kNDim * 8, 16);
     L.off_pair = o; o += align_up(kNPair * 8, 16);
