@@ -23,6 +23,10 @@ fi
 if part prof5; then
 BENCH_FLAGS="--workload cfg5 --steps 1" bash scripts/profile.sh r03_cfg5 > $O/prof_cfg5.log 2>&1 || { cat $O/prof_cfg5.log; exit 3; }; tail -3 $O/prof_cfg5.log
 fi
+if part prof5s; then
+# (counter passes of the full 8192x512x64 workload hung inside the profiler: a 70-row slab of the same layout instead)
+BENCH_FLAGS="--workload cfg5 --rows-per-gpu 70 --steps 1" bash scripts/profile.sh r03_cfg5slab > $O/prof_cfg5slab.log 2>&1 || { cat $O/prof_cfg5slab.log; exit 3; }; tail -3 $O/prof_cfg5slab.log
+fi
 if part marker; then
 rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d $O/marker -- python3 bench.py --workload cfg3 --steps 1 --warmup 1 --no-cpu-baseline > $O/marker.log 2>&1
 find $O/marker -name "*marker*stats*.csv" -o -name "*domain_stats*.csv" | head; f=$(find $O/marker -name "*marker_api_stats.csv" | head -1); [ -n "$f" ] && cat "$f"
