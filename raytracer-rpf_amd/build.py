@@ -37,14 +37,27 @@ def is_stale():
     return _stale(LIB, SOURCES + HEADERS) or not os.path.exists(SCAN_OK)
 
 
-def build(force=False, verbose=False):
-    """one object per translation unit, compiled in parallel, then the link"""
+def build(force=False, verbose=False, defs=(), tag=None):
+    """one object per translation unit, compiled in parallel, then the link.
+    defs / tag: an experiment variant -- extra -D flags, objects under build/obj_<tag>, library lib/librpf_hip_<tag>.so
+    (measured side by side with the shipped library through hip.py's RPF_HIP_LIB; never what tests or bench.py load by default)"""
+    if tag:
+        return _build_variant(list(defs), tag, verbose)
     if not force and not is_stale():
         return LIB
+    return _build(LIB, OBJ_DIR, [], True, force, verbose)
+
+
+def _build_variant(defs, tag, verbose):
+    return _build(os.path.join(_HERE, "lib", "librpf_hip_%s.so" % tag), os.path.join(_ROOT, "build", "obj_" + tag), defs, False, False, verbose)
+
+
+def _build(LIB, OBJ_DIR, defs, shipped, force, verbose):
+    SCAN_OK = os.path.join(OBJ_DIR, "spill_scan.ok")
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     os.makedirs(OBJ_DIR, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
-             "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc")]
+             "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc")] + list(defs)
     objs, procs = [], []
     for src in SOURCES:
         obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
@@ -63,7 +76,7 @@ def build(force=False, verbose=False):
     if asm:
         # the scan's verdict is kept next to the objects (is_stale() wants it) and, when every kernel TU was compiled in this
         # invocation, the per-kernel resource usage of the build goes to profiles/ (tracked: the figures of what ships)
-        full = len(asm) == len(KERNEL_TUS)
+        full = shipped and len(asm) == len(KERNEL_TUS)
         report = os.path.join(_ROOT, "profiles", "r03_resource_usage.txt") if full else os.path.join(OBJ_DIR, "resource_usage_partial.txt")
         chk = subprocess.run([sys.executable, os.path.join(_ROOT, "scripts", "check_spills.py"), "--report", report] + asm,
                              stdout=subprocess.PIPE, text=True)
@@ -112,5 +125,8 @@ def build_host(force=False, verbose=False):
 
 if __name__ == "__main__":
     force = "--force" in sys.argv
+    if "--variant" in sys.argv:  # python build.py --variant <tag> -DNAME=VALUE ...
+        print(build(verbose=True, defs=[a for a in sys.argv[1:] if a.startswith("-D")], tag=sys.argv[sys.argv.index("--variant") + 1]))
+        sys.exit(0)
     print(build(force=force, verbose=True))
     print(build_host(force=force, verbose=True))

@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace rpf {
 namespace xl {
@@ -174,6 +175,42 @@ __device__ __forceinline__ T reduce32(const T (&a)[32], int lane) {
     for (int i = 0; i < 2; ++i) b2[i] = exch_row<Op, kRowHalfMirror, 4>(b4[i], b4[i + 2], lane);
     const T v = exch_row<Op, kQuadXor2, 2>(b2[0], b2[1], lane);
     return allreduce_bit0<Op>(v);
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = I0 .. N-1 (DPP controls are instruction immediates)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// acc += row[lane N of this lane's 16-lane row] * z : a wave-uniform fp64 operand that lives ACROSS the lanes of one register
+// pair (replicated in the four rows) instead of in LDS or in 2 VGPRs per value.  gfx90a+ "DP ALU DPP": 64-bit VOP2 operations
+// take row_newbcast (and nothing else); v_fmac_f64 is VOP2 on gfx950.  Needs EXEC = all lanes (a disabled source lane
+// disables the destination lanes that read it).  NOP: software wait states in front of the first DPP read of a block (a VALU
+// write of the source register -- an AGPR reload, a copy -- within two instructions is a hazard the assembler does not see
+// inside inline asm).  Semantics pinned on MI355X by scripts/microbench/dpp_bcast_probe.hip.
+template <int N, bool NOP = false>
+__device__ __forceinline__ void fmac_rowbc(double &acc, double row, double z) {
+    static_assert(N >= 0 && N < 16, "lane of a 16-lane row");
+    if constexpr (NOP)
+        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(row), "v"(z), "n"(N));
+    else
+        asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(row), "v"(z), "n"(N));
+}
+
+// the value itself (v_mov_b64 is VOP1: DPP-capable)
+template <int N, bool NOP = false>
+__device__ __forceinline__ double rowbc(double row) {
+    static_assert(N >= 0 && N < 16, "lane of a 16-lane row");
+    double out;
+    if constexpr (NOP)
+        asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(row), "n"(N));
+    else
+        asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(row), "n"(N));
+    return out;
 }
 
 } // namespace xl
