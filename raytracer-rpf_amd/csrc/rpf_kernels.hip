@@ -312,6 +312,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun
     uint32_t cells = (uint32_t)bmax * (uint32_t)bmax;
     if (K <= 8 && cells < 512u) cells = 512u; // mi_stage clears with unconditional 1-KiB stores
     if (cells < 256u) cells = 256u;           // the buffer doubles as scratch (stage 1b masks, stage 3c, flags)
+    if (nw > 1) cells += 64u;                 // mi_group V2: one always-zero cell per lane behind the live histogram (its +0 atomics)
     L.hist_stride = align_up(cells * 4u, 1024);   // zero_cells clears whole 1-KiB rows
     o += L.hist_stride * (uint32_t)nw;        // one histogram buffer per wave of the pixel
     if (tun.lds_pad > 0) o += (uint32_t)tun.lds_pad; // occupancy experiment knob
@@ -387,6 +388,7 @@ hipError_t launch_filter_pass(const PassParams &p, const Tuning &tun, hipStream_
     const LdsLayout L = lds_layout(p.S, p.nmax, p.bmax, t_in_lds, tun, p.lay);
     if (lds_bytes_out) *lds_bytes_out = L.total;
     if ((int)L.total > max_lds_per_block()) return hipErrorInvalidValue;
+    if (L.off_T != 0) return hipErrorInvalidValue; // the kernels address the D table (head) through the LDS base itself (sD0)
     const int rows_own = p.row_end - p.row_begin;
     if (rows_own <= 0) return hipSuccess;
     if (p.pix_list != nullptr && p.list_count == 0) return hipSuccess;

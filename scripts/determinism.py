@@ -28,6 +28,16 @@ for k in (1, 2):
         ys, xs = torch.nonzero(diff, as_tuple=True)
         rel = ((outs[0] - outs[k]).abs().amax() / outs[0].abs().amax()).item()
         print("  max abs diff / max: %.3e ; rows %d..%d cols %d..%d" % (rel, ys.min(), ys.max(), xs.min(), xs.max()))
+        try:  # neighbourhood sizes of the differing pixels (which size class / kernel family they ran in)
+            import numpy as np
+            N = np.asarray(ctx.nbhd(W, H)).reshape(H, W)
+            nn = N[ys.cpu().numpy(), xs.cpu().numpy()]
+            edges = [1, 9, 17, 33, 65, 129, 257, 449, 833, 1601, 3137, 1 << 30]  # class c: N <= 8, 16, ..., 3136, more
+            hist_d, _ = np.histogram(nn, bins=edges)
+            hist_a, _ = np.histogram(N.ravel(), bins=edges)
+            print("  N classes (N <= %s, more): differing %s of all %s" % ([e - 1 for e in edges[1:-1]], hist_d.tolist(), hist_a.tolist()))
+        except Exception as e:
+            print("  (nbhd query failed: %s)" % e)
         for i in range(min(nd, 6)):
             y, x = int(ys[i]), int(xs[i])
             d = (outs[0][:, y, x] - outs[k][:, y, x])
