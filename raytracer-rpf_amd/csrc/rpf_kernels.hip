@@ -312,7 +312,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun
     uint32_t cells = (uint32_t)bmax * (uint32_t)bmax;
     if (K <= 8 && cells < 512u) cells = 512u; // mi_stage clears with unconditional 1-KiB stores
     if (cells < 256u) cells = 256u;           // the buffer doubles as scratch (stage 1b masks, stage 3c, flags)
-    if (nw > 1) cells += 64u;                 // mi_group V2: one always-zero cell per lane behind the live histogram (its +0 atomics)
+    if (nw > 1 || K == 13) cells += 64u;                 // mi_group V2: one always-zero cell per lane behind the live histogram (its +0 atomics)
     L.hist_stride = align_up(cells * 4u, 1024);   // zero_cells clears whole 1-KiB rows
     o += L.hist_stride * (uint32_t)nw;        // one histogram buffer per wave of the pixel
     if (tun.lds_pad > 0) o += (uint32_t)tun.lds_pad; // occupancy experiment knob
