@@ -173,10 +173,16 @@ __device__ __forceinline__ void zero_cells(uint32_t *h, int cells, int lane) {
 //   1  kernels with K <= 8 (B = floor(sqrt(N)) <= 22): sample slots 0..5 of a lane are 5-bit fields of ONE 32-bit
 //      word per (column, lane) -- [19][64] words -- and slot 6 is a byte in a side array [19][64] behind them:
 //      6 KiB per pixel, which is what lets 12 single-wave workgroups share a CU's LDS
-//   5  K <= 17 (B <= 32): 5-bit fields, six per word, KW = ceil(K/6) words per (column, lane)
+//   7  K = 13 (B <= 28): slots 0..11 as 5-bit fields of TWO words per (column, lane), slot 12 a byte in a side array
+//      [19][64] behind them (13 x 5 bits are one bit more than two words hold; a third word per (column, lane) was 3.6 KiB
+//      per pixel and, with the table head the kernel no longer keeps, the difference between six and seven resident
+//      workgroups per CU -- this kernel's time goes as 1 / workgroups)
+//   5  other K <= 17 (B <= 32): 5-bit fields, six per word, KW = ceil(K/6) words per (column, lane)
 //   6  larger K (B <= 64): 6-bit fields, five per word, KW = ceil(K/5) words per (column, lane)
-__host__ __device__ constexpr int pack_scheme(int K) { return K <= 8 ? 1 : (K <= 17 ? 5 : 6); }
-__host__ __device__ constexpr int pack_words(int K) { return K <= 8 ? 1 : (K <= 17 ? (K + 5) / 6 : (K + 4) / 5); }
+__host__ __device__ constexpr int pack_scheme(int K) { return K <= 8 ? 1 : (K == 13 ? 7 : (K <= 17 ? 5 : 6)); }
+__host__ __device__ constexpr int pack_words(int K) { return K <= 8 ? 1 : (K == 13 ? 2 : (K <= 17 ? (K + 5) / 6 : (K + 4) / 5)); }
+// bytes of packed bin ids per (column, lane)
+__host__ __device__ constexpr int pack_bytes(int K) { return K <= 8 ? 5 : (K == 13 ? 9 : 4 * pack_words(K)); }
 
 template <int KW, int PACK5>
 struct BinIds {
@@ -192,12 +198,15 @@ struct BinIds {
     __device__ __forceinline__ void set(int kk, uint32_t bin) { // kk is a compile-time constant at every call site
         if constexpr (PACK5 == 1) {
             if (kk < 6) w[0] |= bin << (5 * kk); else b6 = bin;
+        } else if constexpr (PACK5 == 7) {
+            if (kk < 12) w[kk / 6] |= bin << (5 * (kk % 6)); else b6 = bin;
         } else {
             w[kk / SPW] |= bin << (BITS * (kk % SPW));
         }
     }
     __device__ __forceinline__ uint32_t get(int kk) const {
         if constexpr (PACK5 == 1) return kk < 6 ? ((w[0] >> (5 * kk)) & 31u) : b6;
+        else if constexpr (PACK5 == 7) return kk < 12 ? ((w[kk / 6] >> (5 * (kk % 6))) & 31u) : b6;
         else return (w[kk / SPW] >> (BITS * (kk % SPW))) & ((1u << BITS) - 1u);
     }
 };

@@ -289,7 +289,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun
     uint32_t o = 0;
     L.off_T = o;
     if (t_in_lds) o += align_up((uint32_t)nmax * 8u, 16);
-    else if (K <= 13) o += (uint32_t)kDHead * 8u; // the one-wave kernels keep the head of the D table in LDS
+    else if (K <= 8) o += (uint32_t)kDHead * 8u; // the one-wave K <= 8 kernels keep the head of the D table in LDS
     L.off_stat = o; o += align_up(4 * kNDim * 8, 16);
     L.off_hx = o; o += align_up(kNDim * 8, 16);
     L.off_pair = o; o += align_up(kNPair * 8, 16);
@@ -301,8 +301,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun
     L.nw = (uint32_t)nw;
     const uint32_t stage = nw > 1 ? align_up((uint32_t)(nw - 2) * kNDim * (kStageChunk + 1) * 8u, 16) // one chunk per producer wave
                                   : align_up(kNDim * (kStageHalf + 1) * 8, 16);
-    const uint32_t bins = K <= 8 ? align_up((uint32_t)kNDim * kWave * 5u, 16)          // 5-bit words + slot-6 bytes
-                                 : align_up((uint32_t)kNDim * kWave * KW * 4u, 16);     // 5- or 6-bit fields in KW words
+    const uint32_t bins = align_up((uint32_t)kNDim * kWave * (uint32_t)pack_bytes(K), 16); // see BinIds: 5 / 9 / 4 KW bytes per (column, lane)
     uint32_t uni = bins > stage ? bins : stage;
     uint32_t fastz = align_up((uint32_t)S * ((kNWt + 2u) & ~1u) * 8u, 16);               // own rows of the weight stage
     if (nw > 1) fastz += align_up(((uint32_t)S + 1u) / 2u * (2u * ((kNWt + 2u) & ~1u)) * 4u, 16); // + the far-pair screen's fp32 rows, two own samples interleaved
