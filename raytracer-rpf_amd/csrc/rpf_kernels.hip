@@ -294,11 +294,21 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun
     L.off_hx = o; o += align_up(kNDim * 8, 16);
     L.off_pair = o; o += align_up(kNPair * 8, 16);
     L.off_mi = L.off_pair; // the MI values overwrite the pair sums in place
-    L.off_own = o; o += align_up((uint32_t)S * kNDim * 8u, 16);
-    L.off_off = o; o += align_up((uint32_t)nmax * 4u, 16);
-    L.off_union = o;
     const int nw = waves_per_pixel(nmax, tun);
     L.nw = (uint32_t)nw;
+    uint32_t cells = (uint32_t)bmax * (uint32_t)bmax;
+    if (K <= 8 && cells < 512u) cells = 512u; // mi_stage clears with unconditional 1-KiB stores
+    if (cells < 256u) cells = 256u;           // the buffer doubles as scratch (stage 1b masks, stage 3c, flags)
+    if (nw > 1 || K == 13) cells += 64u;      // mi_group V2: one always-zero cell per lane behind the live histogram (its +0 atomics)
+    L.hist_stride = align_up(cells * 4u, 1024);   // zero_cells clears whole 1-KiB rows
+    // The one-wave K = 13 kernel keeps the raw own samples INSIDE its histogram buffer, behind the first KiB (stage 3c / 4's
+    // scratch): nothing reads them between stage 2 and stage 4, and the kernel gathers them again when the histograms are done
+    // (off_own >= off_hist tells it).  2.4 KiB at 16 spp: the eighth resident workgroup of a CU.
+    const uint32_t own_bytes = align_up((uint32_t)S * kNDim * 8u, 16);
+    const bool own_in_hist = K == 13 && nw == 1 && 1024u + own_bytes <= L.hist_stride;
+    L.off_own = o; if (!own_in_hist) o += own_bytes;
+    L.off_off = o; o += align_up((uint32_t)nmax * 4u, 16);
+    L.off_union = o;
     const uint32_t stage = nw > 1 ? align_up((uint32_t)(nw - 2) * kNDim * (kStageChunk + 1) * 8u, 16) // one chunk per producer wave
                                   : align_up(kNDim * (kStageHalf + 1) * 8, 16);
     const uint32_t bins = align_up((uint32_t)kNDim * kWave * (uint32_t)pack_bytes(K), 16); // see BinIds: 5 / 9 / 4 KW bytes per (column, lane)
@@ -308,11 +318,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun
     if (fastz > uni) uni = fastz;
     o += uni;
     L.off_hist = o;
-    uint32_t cells = (uint32_t)bmax * (uint32_t)bmax;
-    if (K <= 8 && cells < 512u) cells = 512u; // mi_stage clears with unconditional 1-KiB stores
-    if (cells < 256u) cells = 256u;           // the buffer doubles as scratch (stage 1b masks, stage 3c, flags)
-    if (nw > 1 || K == 13) cells += 64u;                 // mi_group V2: one always-zero cell per lane behind the live histogram (its +0 atomics)
-    L.hist_stride = align_up(cells * 4u, 1024);   // zero_cells clears whole 1-KiB rows
+    if (own_in_hist) L.off_own = L.off_hist + 1024u;
     o += L.hist_stride * (uint32_t)nw;        // one histogram buffer per wave of the pixel
     if (tun.lds_pad > 0) o += (uint32_t)tun.lds_pad; // occupancy experiment knob
     L.total = o;
