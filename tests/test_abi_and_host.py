@@ -50,6 +50,10 @@ def test_lds_requirement_query(hipmod):
     assert 0 < hipmod.lds_bytes_required(8, 7) <= 64 * 1024
     assert hipmod.lds_bytes_required(8, 7) < hipmod.lds_bytes_required(32, 7) <= 160 * 1024
     assert hipmod.lds_bytes_required(8, 55) == -1  # 24200-sample neighbourhoods: unsupported by this kernel
+    # occupancy of the one-wave kernels is an LDS budget (160 KiB per CU): twelve workgroups of the 8-spp kernel, eight of the
+    # 16-spp one (its time goes as 1 / resident workgroups: 221 -> 180 ms from six to eight)
+    assert hipmod.lds_bytes_required(8, 7) <= 160 * 1024 // 12
+    assert hipmod.lds_bytes_required(16, 7) <= 160 * 1024 // 8
 
 
 def test_product_package_never_imports_the_oracle():
