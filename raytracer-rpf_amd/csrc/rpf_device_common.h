@@ -44,8 +44,13 @@ __device__ __forceinline__ void lds_store_u64_if(bool pred, uint64_t *p, uint64_
     const uint64_t mask = __builtin_amdgcn_ballot_w64(pred);
     const uint32_t addr = (uint32_t)reinterpret_cast<uintptr_t>(p); // LDS byte offset = low half of the flat address
     uint64_t saved;
+    // s_and_saveexec WRITES SCC, and the statement must say so.  Rounds 2-3 shipped it without the clobber: hipcc then keeps a
+    // compare alive across the store wherever that suits its schedule -- seen as wrong pair sums of every histogram group of an
+    // anchor after its first in the one-wave K = 25 / 49 kernels, and as run-to-run differences with a table head at K = 13
+    // (both layouts), while the instantiations that shipped happened to compare after the store (scripts/r03_diag_mi.py,
+    // r03_bisect.sh, r03_bisect2.sh; gpurun_out/r3v: 73 of 99 pixels wrong without, 0 with the clobber).
     asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, %0"
-                 : "=&s"(saved) : "s"(mask), "v"(addr), "v"(v) : "memory");
+                 : "=&s"(saved) : "s"(mask), "v"(addr), "v"(v) : "memory", "scc");
 }
 
 __device__ __forceinline__ uint32_t fnv1a_u32(uint32_t h, uint32_t v) {

@@ -299,7 +299,7 @@ LdsLayout lds_layout(int S, int nmax, int bmax, bool t_in_lds, const Tuning &tun
     uint32_t cells = (uint32_t)bmax * (uint32_t)bmax;
     if (K <= 8 && cells < 512u) cells = 512u; // mi_stage clears with unconditional 1-KiB stores
     if (cells < 256u) cells = 256u;           // the buffer doubles as scratch (stage 1b masks, stage 3c, flags)
-    if (nw > 1 || K == 13) cells += 64u;      // mi_group V2: one always-zero cell per lane behind the live histogram (its +0 atomics)
+    if (K > 8 || !lay.is_ref19()) cells += 64u;      // mi_group V2: one always-zero cell per lane behind the live histogram (its +0 atomics)
     L.hist_stride = align_up(cells * 4u, 1024);   // zero_cells clears whole 1-KiB rows
     // The one-wave K = 13 kernel keeps the raw own samples INSIDE its histogram buffer, behind the first KiB (stage 3c / 4's
     // scratch): nothing reads them between stage 2 and stage 4, and the kernel gathers them again when the histograms are done
