@@ -151,3 +151,28 @@ def test_optional_integrator_parameters(hipmod):
     assert st == -1 and "at most 8" in msg
     st, _, _, msg = parse([7], "cuda")
     assert st == -1 and "cuda" in msg
+
+
+def test_inline_asm_declares_the_status_registers_it_writes():
+    """An asm statement whose SALU instructions write SCC (or that writes VCC / EXEC by name) must say so in its clobber list:
+    without it hipcc may keep a compare alive across the statement -- round 3 traced wrong histogram sums in some kernel
+    instantiations to exactly that (lds_store_u64_if: s_and_saveexec_b64 writes SCC)."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "raytracer-rpf_amd", "csrc")
+    scc_writers = re.compile(r"\bs_(and|or|xor|andn2|orn2|nand|nor|xnor|not|add|sub|addc|subb|min|max|mul_hi|lshl|lshr|ashr|bfe|bfm|"
+                             r"abs|cmp|cmpk|bitcmp|cselect|wqm|quadmask|bcnt|ff|flbit|sext|absdiff)\w*\b")
+    bad = []
+    for path in sorted(glob.glob(os.path.join(csrc, "*"))):
+        text = open(path, errors="replace").read()
+        for m in re.finditer(r"\basm\s*(volatile)?\s*\(", text):
+            depth, i = 1, m.end()
+            while depth and i < len(text):
+                depth += {"(": 1, ")": -1}.get(text[i], 0)
+                i += 1
+            stmt = text[m.start():i]
+            strings = " ".join(re.findall(r'"((?:[^"\\]|\\.)*)"', stmt))
+            writes_scc = bool(scc_writers.search(strings)) or "saveexec" in strings
+            if writes_scc and '"scc"' not in stmt:
+                bad.append("%s: %s" % (os.path.basename(path), stmt[:90].replace("\n", " ")))
+    assert not bad, bad
