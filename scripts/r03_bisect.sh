@@ -1,4 +1,6 @@
 #!/bin/bash
+# (historical: the variant libraries were builds with bisecting macros -- build.py --variant <tag> -D... -- that the source no
+# longer carries; the fault they chased was the missing scc clobber of lds_store_u64_if)
 # determinism of the 32-spp split route on the shipped build and on variant libraries (bisecting a run-to-run difference)
 export TMPDIR=/tmp
 O=gpurun_out/${TAG:-r3j}

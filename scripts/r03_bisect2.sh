@@ -1,4 +1,6 @@
 #!/bin/bash
+# (historical: the variant libraries were builds with bisecting macros -- build.py --variant <tag> -D... -- that the source no
+# longer carries; the fault they chased was the missing scc clobber of lds_store_u64_if)
 # the V2 form of mi_group in the one-wave K = 25 kernel (option waves_per_pixel 1), variant libraries: which ingredient breaks it
 export TMPDIR=/tmp
 O=gpurun_out/r3v
