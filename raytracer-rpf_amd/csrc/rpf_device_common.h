@@ -169,6 +169,9 @@ __device__ __forceinline__ void zero_cells(uint32_t *h, int cells, int lane) {
         // 1 KiB (lds_layout).  A per-lane bound makes this a divergent loop, and at the register pressure of the
         // large-K kernels hipcc parked spill copies behind its exit, where EXEC is empty (check_spills.py).
         const int nit = __builtin_amdgcn_readfirstlane((cells + kWave * 4 - 1) / (kWave * 4));
+        // (no loop vectoriser here: it turned the 16-byte store per row into four 4-byte stores -- 24 LDS instructions per
+        // histogram of the 32-spp class instead of 6)
+#pragma clang loop vectorize(disable) interleave(disable)
         for (int it = 0; it < nit; ++it) *reinterpret_cast<uint4 *>(h + (it * kWave + lane) * 4) = make_uint4(0u, 0u, 0u, 0u);
     }
 }
